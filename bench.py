@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Headline benchmark: decode tokens/s of the batched decode hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (config.workload): BASELINE.json configs[1] -- LLaMA-2-7B, W8A16 weights, int8 group-8 KV cache
+(cache_layout 3, cache_mode 0), tensor parallel over the N GPUs, running batch 1024, every request at context
+length --kv-len (512 = the mean of a 1024-token sequence) when the timed region starts; synthetic weights and
+synthetic KV history generated on the device (no checkpoints/datasets are available offline).  One "step" is one
+pass of the hot path over the batch: pplhip_set_inputs -> pplhip_run (32 layers) -> pplhip_sample (greedy), i.e.
+LLMEngine::Execute (reference src/engine/llm_engine.cc:171-236); each step emits 1024 tokens.
+value = 1024 * K / (max over ranks of the wall time of the K timed steps).
+
+Extra objects on the JSON line:
+  roofline     -- the dominant kernel (decode attention): algorithmic KV bytes / HIP-event duration vs 8 TB/s
+  cpu_baseline -- the CPU restatement (oracle/, "port") timed on the host cores, on a bounded sample
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def load_pplhip():
+    spec = importlib.util.spec_from_file_location("pplhip_binding", os.path.join(ROOT, "ppl.llm.serving_amd", "pplhip.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["pplhip_binding"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+MODELS = {
+    "llama2-7b": dict(hidden_dim=4096, intermediate_dim=11008, num_layers=32, num_heads=32, num_kv_heads=32, vocab_size=32000),
+    "llama2-13b": dict(hidden_dim=5120, intermediate_dim=13824, num_layers=40, num_heads=40, num_kv_heads=40, vocab_size=32000),
+    "llama2-70b": dict(hidden_dim=8192, intermediate_dim=28672, num_layers=80, num_heads=64, num_kv_heads=8, vocab_size=32000),
+}
+
+
+def attn_bytes_per_launch(B, kv_lens_sum, H, Hkv, D, kv_quant):
+    """per layer  sum_b kv_len_b * 2 * Hkv * (D*e + (D/8)*2 [int8])  +  B*H*D*2*2 (q read, o write)."""
+    per_tok = 2 * Hkv * (D * (1 if kv_quant else 2) + ((D // 8) * 2 if kv_quant else 0))
+    return kv_lens_sum * per_tok + B * H * D * 2 * 2
+
+
+def cpu_baseline(model_kw, kv_len, budget_s=25.0):
+    """the oracle (CPU restatement, 'port') on a bounded sample: decode steps of a batch of 8 at the same kv_len."""
+    from oracle import ref
+    B = 8
+    desc = ref.make_desc(max_position=2048, cache_quant_bit=8, cache_quant_group=8, cache_layout=3, cache_mode=0,
+                         weight_quant_bit=8, **model_kw)
+    t0 = time.time()
+    m = ref.RefModel(desc)
+    m.init_synthetic(1234)
+    tokens = B * (kv_len + 8)
+    m.kv_alloc(tokens)
+    kc, ks = m.kv_array(0), m.kv_array(1)
+    rng = np.random.RandomState(0)
+    kc[:] = rng.randint(-127, 128, size=kc.size, dtype=np.int8)
+    ks[:] = (0.01 + 0.02 * rng.rand(ks.size)).astype(np.float16)
+    setup_s = time.time() - t0
+    cache_idx = (np.arange(B) * (kv_len + 8)).astype(np.int64)
+    tok = rng.randint(3, desc.vocab_size, size=B).astype(np.int64)
+    steps, t_total = 0, 0.0
+    while steps < 4 and (steps == 0 or t_total + t_total / steps < budget_s):
+        st = ref.make_step(tok, np.arange(B + 1), np.full(B, kv_len + steps), cache_idx, B)
+        t1 = time.time()
+        logits = ref.forward([m], st)
+        tok = logits.argmax(-1).astype(np.int64)
+        t_total += time.time() - t1
+        steps += 1
+    cores = ref.lib().ref_num_threads()
+    m.close()
+    return {"value": round(B * steps / t_total, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} decode steps of batch {B} at kv_len {kv_len}, same 7B W8A16/int8-KV config "
+                      f"(oracle/llama_ref.c, OpenMP; setup {setup_s:.1f}s not timed)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="llama2-7b", choices=sorted(MODELS))
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--kv-len", type=int, default=512)
+    ap.add_argument("--weight-quant", type=int, default=8)
+    ap.add_argument("--kv-quant", type=int, default=8)
+    ap.add_argument("--layers", type=int, default=0, help="debug only: override the layer count (result is then INVALID)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tpb", type=int, default=0)
+    ap.add_argument("--prefill-sample", type=int, default=1, help="also time one 8192-token prefill step (TTFT proxy)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    P = load_pplhip()
+    mk = dict(MODELS[args.model])
+    if args.layers:
+        mk["num_layers"] = args.layers
+    B, K, W = args.batch, args.steps, args.warmup
+    total_len = args.kv_len + K + W + 2
+    desc = P.make_desc(max_position=max(2048, total_len + 1), cache_quant_bit=args.kv_quant,
+                       cache_quant_group=8 if args.kv_quant else 1, cache_layout=3, cache_mode=0,
+                       weight_quant_bit=args.weight_quant, **mk)
+    uid = None
+    if world > 1:
+        box = [P.get_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+    ctx = P.Context(desc, max_running_batch=B, max_tokens_per_step=max(8192, B), n_local_ranks=1, world_size=world,
+                    rank_base=rank, device_ids=[local_rank], unique_id=uid, profiling=True, tpb=args.tpb)
+    ctx.init_synthetic(0, 1234)
+    kv_tokens = B * total_len
+    cap = ctx.kv_capacity(0.94)
+    if kv_tokens > cap:
+        sys.exit(f"KV slab needs {kv_tokens} tokens but only {cap} fit")
+    ctx.kv_alloc(0, kv_tokens)
+    ctx.kv_fill_synthetic(0, 99)
+    H, Hkv, D = desc.num_heads // world, desc.num_kv_heads // world, desc.hidden_dim // desc.num_heads
+
+    rng = np.random.RandomState(1234)
+    cache_idx = (np.arange(B, dtype=np.int64) * total_len)
+    seq_starts = np.arange(B + 1, dtype=np.int64)
+    tok = rng.randint(3, desc.vocab_size, size=B).astype(np.int64)
+
+    def barrier():
+        ctx.sync(0)
+        if dist is not None:
+            dist.barrier()
+
+    def step(i, tok):
+        st = P.make_step(tok, seq_starts, np.full(B, args.kv_len + i, dtype=np.int64), cache_idx, B,
+                         req_list_changed=1 if i == 0 else 0)
+        ctx.set_inputs(0, st)
+        ctx.run(0)
+        out, _ = ctx.sample(B, top_k=1, req_list_changed=(i == 0))
+        return out.astype(np.int64)
+
+    for i in range(W):
+        tok = step(i, tok)
+    barrier()
+    ctx.profile_reset(0)
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        tok = step(i, tok)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    n_attn, ms_attn = ctx.profile_get(P.PROF_ATTN_DECODE)
+    n_gemm, ms_gemm = ctx.profile_get(P.PROF_GEMM)
+    n_run, ms_run = ctx.profile_get(P.PROF_RUN)
+    kv_sum = sum(B * (args.kv_len + i + 1) for i in range(W, W + K))  # keys read per layer over the timed steps
+    bytes_total = attn_bytes_per_launch(B * K, kv_sum, H, Hkv, D, args.kv_quant) * desc.num_layers
+    achieved = bytes_total / (ms_attn * 1e-3) / 1e9 if ms_attn > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "attn_decode_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    extra = {}
+    if args.prefill_sample:
+        # TTFT proxy: one admission step of 16 x 512-token prompts (max_tokens_per_step 8192), cold cache slots
+        nreq, plen = 16, 512
+        if nreq * plen <= kv_tokens:
+            ptok = rng.randint(3, desc.vocab_size, size=nreq * plen).astype(np.int64)
+            st = P.make_step(ptok, np.arange(nreq + 1) * plen, np.zeros(nreq, dtype=np.int64),
+                             (np.arange(nreq, dtype=np.int64) * total_len), 0)
+            for rep in range(2):
+                barrier()
+                t1 = time.perf_counter()
+                ctx.set_inputs(0, st)
+                ctx.run(0)
+                ctx.sample(nreq, top_k=1)
+                barrier()
+                dt = time.perf_counter() - t1
+            extra = {"prefill_step_ms": round(dt * 1e3, 3), "prefill_tokens_per_s": round(nreq * plen / dt, 1),
+                     "prefill_shape": f"{nreq} prompts x {plen} tokens in one step"}
+
+    if rank == 0:
+        res = {
+            "metric": "decode tokens/sec, LLaMA-7B int8 (W8A16), max-running-batch 1024",
+            "value": round(B * K / elapsed, 2), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "fp16 activations, int8 weights (W8A16), int8-g8 KV, fp32 accumulate",
+            "data": "synthetic (device-generated weights and KV history, random token ids)",
+            "config": {"workload": f"{args.model} W{args.weight_quant or 16}A16 decode, batch {B}, kv_len {args.kv_len}"
+                                   f"..{args.kv_len + K + W}, greedy top_k=1, cache_layout 3 / cache_mode 0, "
+                                   f"kv int{args.kv_quant or 16}", "global_batch": B, "seq_len": 1024,
+                       "parallelism": f"tp{world}", "layers": desc.num_layers},
+            "roofline": {"kernel": "attn_decode_kernel<8,128>" if args.kv_quant else "attn_decode_kernel<0,128>",
+                         "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                         "launches": n_attn, "avg_launch_ms": round(ms_attn / max(n_attn, 1), 4),
+                         "algorithmic_bytes_per_launch": int(bytes_total / max(n_attn, 1))},
+            "breakdown_ms_per_step": {"attn_decode": round(ms_attn / K, 3), "gemm": round(ms_gemm / K, 3),
+                                      "run_total_gpu": round(ms_run / K, 3)},
+        }
+        res.update(extra)
+        if args.layers:
+            res["INVALID"] = "layer count overridden for debugging"
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(mk, args.kv_len)
+            except Exception as e:  # the baseline is reporting only; never hide the GPU result
+                res["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(res), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -191,6 +191,11 @@ PPLHIP_API int pplhip_kv_read(pplhip_ctx* ctx, int rank, int which, uint64_t off
 PPLHIP_API int pplhip_kv_write(pplhip_ctx* ctx, int rank, int which, uint64_t offset, const void* src,
                                uint64_t bytes);
 
+/* test/benchmark: fills the whole slab with pseudo-random history (int8 bytes / fp16 values from the
+ * counter-based generator, scales in [0.01, 0.03)) so that decode steps can be measured at a given context
+ * length without running the prefill first. */
+PPLHIP_API int pplhip_kv_fill_synthetic(pplhip_ctx* ctx, int rank, uint64_t seed);
+
 /* ================================================================================================
  * the step -- replaces SetInputTask / RunModelTask (src/engine/llm_engine.cc:29-116)
  * ============================================================================================== */

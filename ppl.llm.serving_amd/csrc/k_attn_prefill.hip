@@ -1,0 +1,240 @@
+// K6 / K7 MultiHeadCacheAttention, prefill and cache-prefill (prefix-cache hit) phases: the new tokens of a
+// request attend causally to cache positions [0, start_pos + i].  K and V are read back from the KV slab
+// (after K5 wrote them), so a cold prefill, a prefix-cache hit (start_pos > 0, ENGINE_CONF_CACHE_PREFILL,
+// src/engine/llm_engine.cc:114) and a 1-token request all run this one kernel.  MFMA-bound.
+//
+// Work decomposition (wave64, gfx950, mfma_f32_16x16x32_f16):
+//   grid  = (ceil(max_seq_len / 64), requests, H); block = 4 waves; wave w owns 16 query rows.
+//   per KV tile of 64 keys:  K tile -> LDS as fp16 [key][D] (16-B chunks XOR-swizzled against bank conflicts),
+//                            V tile -> LDS TRANSPOSED [d][key] (key-pair dwords, XOR-swizzled) because the PV
+//                            MFMA contracts over keys and needs them contiguous per lane.
+//   S^T = K . Q^T  (A = K fragment from LDS, B = Q fragment in registers): the C layout then gives every lane
+//   16 scores of ONE query row (col = lane&15), so the online softmax is lane-local plus two xor-shuffles and
+//   the probabilities are already in MFMA A-operand order for O += P . V (the k-slot permutation this implies
+//   is applied identically to the V^T reads).
+//   int8 KV is dequantised to fp16 while staging (one fp16 rounding of q*scale; DESIGN.md "numerics").
+// Oracle: ref_attention (oracle/llama_ref.c).
+#include "kernels.h"
+
+namespace pplhip {
+
+constexpr int PF_BM = 64;   // query rows per block
+constexpr int PF_BN = 64;   // keys per tile
+constexpr int PF_VS = 34;   // dword stride of a V^T row (64 keys = 32 dwords + 2 pad)
+
+template <int D>
+__device__ __forceinline__ int k_swz(int key) {
+    constexpr int CPR = D / 8;                         // 16-B chunks per row
+    constexpr int RPW = (128 / D) > 0 ? (128 / D) : 1; // rows per 256-B bank window
+    return (key / RPW) % CPR;
+}
+__device__ __forceinline__ int v_swz(int ch) { return ((ch >> 4) & 7) << 2; }
+
+template <int QBIT, int D>
+__global__ __launch_bounds__(256) void attn_prefill_kernel(const uint16_t* __restrict__ qkv, KvAddr kv,
+                                                           const int64_t* __restrict__ seq_starts,
+                                                           const int64_t* __restrict__ start_pos,
+                                                           const int64_t* __restrict__ cache_indices, int64_t max_pages,
+                                                           int64_t b0, int H, int Hkv, uint16_t* __restrict__ out) {
+    constexpr int ELT = QBIT == 8 ? 1 : 2;
+    constexpr int CH = 16 / ELT;
+    constexpr int LPT = D / CH;
+    constexpr int KSTEPS = D / 32;
+    constexpr int DT = D / 16;
+    __shared__ __attribute__((aligned(16))) uint16_t Ks[PF_BN * D];
+    __shared__ __attribute__((aligned(16))) uint32_t Vt[D * PF_VS];
+
+    const int64_t b = b0 + blockIdx.y;
+    const int hq = blockIdx.z;
+    const int hk = hq / (H / Hkv);
+    const int64_t seqlen = seq_starts[b + 1] - seq_starts[b];
+    const int64_t q0 = (int64_t)blockIdx.x * PF_BM;
+    if (q0 >= seqlen) return;
+    const int64_t sp = start_pos[b];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int64_t rowstride = (int64_t)(H + 2 * Hkv) * D;
+
+    // Q fragments: B operand, lane (n = query row l15, kq) holds Q[row][ks*32 + kq*8 .. +8]
+    int64_t qi = q0 + wave * 16 + l15;
+    const bool qvalid = qi < seqlen;
+    if (!qvalid) qi = seqlen - 1;
+    const int64_t qpos = sp + qi;
+    const uint16_t* qrow = qkv + (seq_starts[b] + qi) * rowstride + (int64_t)hq * D;
+    h8 qf[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(qrow + ks * 32 + kq * 8));
+
+    f4 o[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[i] = f4{0.f, 0.f, 0.f, 0.f};
+    float m = -1e30f, l = 0.f;
+    const float sm_scale = 1.0f / sqrtf((float)D);
+
+    const int64_t last_q = (q0 + PF_BM - 1 < seqlen - 1) ? q0 + PF_BM - 1 : seqlen - 1;
+    const int64_t kv_end = sp + last_q + 1;   // keys needed by this block: [0, kv_end)
+    const int ntiles = (int)((kv_end + PF_BN - 1) / PF_BN);
+
+    const char* kbase = reinterpret_cast<const char*>(kv.cache) + (int64_t)hk * kv.sH * ELT;
+    const char* vbase = kbase + kv.sKV * ELT;
+    const uint16_t* ksbase = kv.scale + (int64_t)hk * kv.ssH;
+    const uint16_t* vsbase = ksbase + kv.ssKV;
+
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int64_t key0 = (int64_t)tile * PF_BN;
+        // ---- stage K (row-major, swizzled) and V (transposed) ----------------------------------------
+        for (int item = threadIdx.x; item < 32 * LPT; item += 256) {
+            const int c = item % LPT, kp = item / LPT;
+            const int ch0 = c * CH;
+            float kf[2][CH], vf[2][CH];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                int64_t key = key0 + 2 * kp + e;
+                if (key >= kv_end) key = kv_end - 1;
+                const int64_t slot = kv_slot(kv, cache_indices, max_pages, b, key);
+                const uint4 kr = *reinterpret_cast<const uint4*>(kbase + (slot * kv.sN + ch0) * ELT);
+                const uint4 vr = *reinterpret_cast<const uint4*>(vbase + (slot * kv.sN + ch0) * ELT);
+                if constexpr (QBIT == 8) {
+                    const uint32_t kw[4] = {kr.x, kr.y, kr.z, kr.w}, vw[4] = {vr.x, vr.y, vr.z, vr.w};
+#pragma unroll
+                    for (int gi = 0; gi < 2; ++gi) {
+                        const float ks_ = h2f(ksbase[slot * kv.ssN + ch0 / 8 + gi]);
+                        const float vs_ = h2f(vsbase[slot * kv.ssN + ch0 / 8 + gi]);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int idx = gi * 8 + i;
+                            kf[e][idx] = (float)(int8_t)(kw[idx >> 2] >> (8 * (idx & 3))) * ks_;
+                            vf[e][idx] = (float)(int8_t)(vw[idx >> 2] >> (8 * (idx & 3))) * vs_;
+                        }
+                    }
+                } else {
+                    unpack8(kr, kf[e]);
+                    unpack8(vr, vf[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int key = 2 * kp + e;
+#pragma unroll
+                for (int cc = 0; cc < CH / 8; ++cc) {
+                    const int chunk = (ch0 / 8 + cc) ^ k_swz<D>(key);
+                    *reinterpret_cast<uint4*>(&Ks[key * D + chunk * 8]) = pack8(&kf[e][cc * 8]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int ch = ch0 + i;
+                const h2 pr = {(_Float16)vf[0][i], (_Float16)vf[1][i]};
+                Vt[ch * PF_VS + (kp ^ v_swz(ch))] = __builtin_bit_cast(uint32_t, pr);
+            }
+        }
+        __syncthreads();
+
+        // ---- S^T = K . Q^T : 4 key tiles of 16 --------------------------------------------------------
+        f4 sacc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sacc[j] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int key = j * 16 + l15;
+                const int chunk = (ks * 4 + kq) ^ k_swz<D>(key);
+                const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&Ks[key * D + chunk * 8]));
+                sacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[ks], sacc[j], 0, 0, 0);
+            }
+        }
+        // ---- online softmax for query row l15; this lane holds keys j*16 + kq*4 + r ---------------------
+        float p[4][4];
+        float mx = -1e30f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t kpos = key0 + j * 16 + kq * 4 + r;
+                const float sv = (kpos <= qpos) ? sacc[j][r] * sm_scale : -1e30f;
+                p[j][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(m, mx);
+        const float alpha = __expf(m - mnew);
+        m = mnew;
+        float rs = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t kpos = key0 + j * 16 + kq * 4 + r;
+                const float e = (kpos <= qpos) ? __expf(p[j][r] - mnew) : 0.f;
+                p[j][r] = e;
+                rs += e;
+            }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l = l * alpha + rs;
+        // rescale O: its C layout has rows (kq*4 + r) -> fetch alpha of those query rows
+        float ar[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, kq * 4 + r, 64);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dt][r] *= ar[r];
+        // ---- O += P . V : A = P (this lane's 8 keys per k-step: tiles 2s, 2s+1), B = V^T from LDS ---------
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            h8 pa;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pa[r] = (_Float16)p[2 * s2][r];
+                pa[4 + r] = (_Float16)p[2 * s2 + 1][r];
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int ch = dt * 16 + l15;
+                const int p0 = (8 * (2 * s2) + kq * 2) ^ v_swz(ch);      // dword index of keys 16*(2s)+kq*4
+                const int p1 = (8 * (2 * s2 + 1) + kq * 2) ^ v_swz(ch);
+                const uint2 lo = *reinterpret_cast<const uint2*>(&Vt[ch * PF_VS + p0]);
+                const uint2 hi = *reinterpret_cast<const uint2*>(&Vt[ch * PF_VS + p1]);
+                const h8 bv = __builtin_bit_cast(h8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, bv, o[dt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: O / l, fp16, rows kq*4 + r of this wave -------------------------------------------------
+    float lr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lr[r] = __shfl(l, kq * 4 + r, 64);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t qrow_i = q0 + wave * 16 + kq * 4 + r;
+        if (qrow_i < seqlen) {
+            uint16_t* orow = out + ((seq_starts[b] + qrow_i) * H + hq) * (int64_t)D;
+            const float inv = 1.0f / lr[r];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) orow[dt * 16 + l15] = f2h(o[dt][r] * inv);
+        }
+    }
+}
+
+hipError_t launch_attn_prefill(hipStream_t s, const uint16_t* qkv, const KvAddr& kv, int quant_bit,
+                               const int64_t* seq_starts, const int64_t* start_pos, const int64_t* cache_indices,
+                               int64_t max_pages, int64_t b0, int64_t B, int H, int Hkv, int D, int64_t max_seq_len,
+                               uint16_t* out) {
+    if (B <= b0 || max_seq_len <= 0) return hipSuccess;
+    dim3 grid((unsigned)((max_seq_len + PF_BM - 1) / PF_BM), (unsigned)(B - b0), (unsigned)H);
+#define PF_CASE(QB, DD)                                                                                          \
+    if (quant_bit == QB && D == DD) {                                                                            \
+        hipLaunchKernelGGL((attn_prefill_kernel<QB, DD>), grid, dim3(256), 0, s, qkv, kv, seq_starts, start_pos, \
+                           cache_indices, max_pages, b0, H, Hkv, out);                                           \
+        return hipGetLastError();                                                                                \
+    }
+    PF_CASE(8, 128) PF_CASE(0, 128) PF_CASE(8, 64) PF_CASE(0, 64) PF_CASE(8, 32) PF_CASE(0, 32)
+#undef PF_CASE
+    return hipErrorInvalidValue;
+}
+
+}  // namespace pplhip

@@ -1,0 +1,78 @@
+// Device-side helpers shared by the gfx950 kernels (wave64, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+namespace pplhip {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+__device__ __forceinline__ float round_h(float f) { return (float)(_Float16)f; }
+
+// 16-byte vector of 8 halfs <-> floats
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+    const h8 h = __builtin_bit_cast(h8, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)h[i];
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    h8 h;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = (_Float16)f[i];
+    return __builtin_bit_cast(uint4, h);
+}
+
+// KV slab addressing (src/engine/llm_engine.cc:118-169): element strides of (layer, k/v, head, token)
+// for the four cache layouts; `d` is the innermost extent (head_dim, or head_dim/group for scales).
+struct KvStrides {
+    int64_t sL, sKV, sH, sN;
+};
+__host__ __device__ inline KvStrides kv_strides(int layout, int64_t N, int64_t L, int64_t h, int64_t d) {
+    KvStrides s;
+    switch (layout) {
+        case 0: s.sN = L * 2 * h * d; s.sL = 2 * h * d; s.sKV = h * d; s.sH = d; break;
+        case 1: s.sL = N * 2 * h * d; s.sN = 2 * h * d; s.sKV = h * d; s.sH = d; break;
+        case 2: s.sL = 2 * N * h * d; s.sKV = N * h * d; s.sN = h * d; s.sH = d; break;
+        default: s.sL = 2 * h * N * d; s.sKV = h * N * d; s.sH = N * d; s.sN = d; break;
+    }
+    return s;
+}
+
+// everything an attention / cache-write kernel needs to find K/V rows of one layer
+struct KvAddr {
+    void* cache;        // fp16 or int8 base of this LAYER's K plane (kv = 0); V plane = + sKV
+    uint16_t* scale;    // fp16 scales, same convention
+    int64_t sKV, sH, sN;       // element strides in the cache
+    int64_t ssKV, ssH, ssN;    // element strides in the scale slab
+    int32_t mode, page_size;   // cache_mode (0 contiguous / 1 paged)
+};
+
+// KV slot of (request b, position pos): mode 0 cache_indices[b] + pos; mode 1 paged
+// (src/generator/llm_generator.cc:487,553-554; llm_engine.cc:64-71)
+__device__ __forceinline__ int64_t kv_slot(const KvAddr& a, const int64_t* __restrict__ cache_indices, int64_t max_pages,
+                                           int64_t b, int64_t pos) {
+    if (a.mode == 0) return cache_indices[b] + pos;
+    const int64_t pg = pos / a.page_size;
+    return cache_indices[b * max_pages + pg] * a.page_size + (pos - pg * a.page_size);
+}
+
+}  // namespace pplhip

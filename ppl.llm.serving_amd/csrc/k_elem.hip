@@ -1,0 +1,113 @@
+// K1 embedding gather, K2 (Skip)RMSNorm (+ last-token gather of K11), K10 SwiGLU -- HBM-bound row kernels.
+// One 256-thread workgroup per row, 16-byte (8 x fp16) accesses per lane, fp32 arithmetic.
+// Semantics: DESIGN.md "numerics"; oracle: ref_embedding / ref_rmsnorm / ref_silu_mul (oracle/llama_ref.c).
+#include "kernels.h"
+
+namespace pplhip {
+
+__global__ __launch_bounds__(256) void embedding_kernel(const int64_t* __restrict__ ids, const uint4* __restrict__ table,
+                                                        int chunks /* hidden/8 */, uint4* __restrict__ out) {
+    const int64_t t = blockIdx.x;
+    const int64_t row = ids[t];
+    for (int c = threadIdx.x; c < chunks; c += 256) out[t * chunks + c] = table[row * chunks + c];
+}
+
+hipError_t launch_embedding(hipStream_t s, const int64_t* token_ids, const uint16_t* table, int64_t T, int hidden,
+                            uint16_t* out) {
+    if (T == 0) return hipSuccess;
+    hipLaunchKernelGGL(embedding_kernel, dim3((unsigned)T), dim3(256), 0, s, token_ids, (const uint4*)table, hidden / 8,
+                       (uint4*)out);
+    return hipGetLastError();
+}
+
+// Each thread keeps up to MAXC chunks of its row in registers (hidden <= 256*8*MAXC); larger rows re-read.
+template <int MAXC>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const uint4* x /* may alias residual_out */, const uint4* __restrict__ skip,
+                                                      const uint4* __restrict__ w, float eps, int chunks, int hidden,
+                                                      const int64_t* __restrict__ gather, uint4* __restrict__ out,
+                                                      uint4* residual_out) {
+    __shared__ float red[4];
+    const int64_t r = blockIdx.x;
+    const int64_t src = gather ? gather[r + 1] - 1 : r;
+    float v[MAXC][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = threadIdx.x + i * 256;
+        if (c < chunks) {
+            unpack8(x[src * chunks + c], v[i]);
+            if (skip) {
+                float sk[8];
+                unpack8(skip[src * chunks + c], sk);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[i][j] = round_h(v[i][j] + sk[j]);
+                if (residual_out) residual_out[r * chunks + c] = pack8(v[i]);
+            } else if (residual_out) {
+                residual_out[r * chunks + c] = pack8(v[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += v[i][j] * v[i][j];
+        }
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    ss = red[0] + red[1] + red[2] + red[3];
+    const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = threadIdx.x + i * 256;
+        if (c < chunks) {
+            float wf[8], o[8];
+            unpack8(w[c], wf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = v[i][j] * inv * wf[j];
+            out[r * chunks + c] = pack8(o);
+        }
+    }
+}
+
+hipError_t launch_rmsnorm(hipStream_t s, const uint16_t* x, const uint16_t* skip, const uint16_t* w, float eps,
+                          int64_t rows, int hidden, const int64_t* gather_seq_starts, uint16_t* out,
+                          uint16_t* residual_out) {
+    if (rows == 0) return hipSuccess;
+    const int chunks = hidden / 8;
+    if (hidden % 8 || chunks > 256 * 8) return hipErrorInvalidValue;
+    dim3 g((unsigned)rows), b(256);
+#define RMS_LAUNCH(MC)                                                                                              \
+    hipLaunchKernelGGL(rmsnorm_kernel<MC>, g, b, 0, s, (const uint4*)x, (const uint4*)skip, (const uint4*)w, eps,   \
+                       chunks, hidden, gather_seq_starts, (uint4*)out, (uint4*)residual_out)
+    if (chunks <= 256) RMS_LAUNCH(1);
+    else if (chunks <= 512) RMS_LAUNCH(2);
+    else if (chunks <= 1024) RMS_LAUNCH(4);
+    else RMS_LAUNCH(8);
+#undef RMS_LAUNCH
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void silu_mul_kernel(const uint4* __restrict__ gu, int64_t total_chunks, int ichunks,
+                                                       uint4* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_chunks; i += (int64_t)gridDim.x * 256) {
+        const int64_t t = i / ichunks;
+        const int c = (int)(i - t * ichunks);
+        float g[8], u[8], o[8];
+        unpack8(gu[t * 2 * ichunks + c], g);
+        unpack8(gu[t * 2 * ichunks + ichunks + c], u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = g[j] / (1.0f + __expf(-g[j])) * u[j];
+        out[i] = pack8(o);
+    }
+}
+
+hipError_t launch_silu_mul(hipStream_t s, const uint16_t* gate_up, int64_t T, int inter, uint16_t* out) {
+    if (T == 0) return hipSuccess;
+    if (inter % 8) return hipErrorInvalidValue;
+    const int64_t total = T * (inter / 8);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const uint4*)gate_up, total, inter / 8,
+                       (uint4*)out);
+    return hipGetLastError();
+}
+
+}  // namespace pplhip

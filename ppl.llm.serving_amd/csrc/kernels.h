@@ -1,0 +1,65 @@
+// Host-callable launchers of the hand-written gfx950 kernels.  All pointers are device pointers, all
+// launches are asynchronous on `stream`.  Return value: hipError_t of the launch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "k_common.h"
+
+namespace pplhip {
+
+// ---- k_elem.hip -------------------------------------------------------------------------------
+hipError_t launch_embedding(hipStream_t s, const int64_t* token_ids, const uint16_t* table, int64_t T, int hidden,
+                            uint16_t* out);
+// out[r] = rmsnorm(x[src(r)] (+ skip[src(r)])) * w.  gather_seq_starts != NULL: src(r) = seq_starts[r+1]-1
+// (last-token gather of K11), else src(r) = r.  residual_out (optional) receives fp16(x + skip) at row r.
+hipError_t launch_rmsnorm(hipStream_t s, const uint16_t* x, const uint16_t* skip, const uint16_t* w, float eps,
+                          int64_t rows, int hidden, const int64_t* gather_seq_starts, uint16_t* out,
+                          uint16_t* residual_out);
+hipError_t launch_silu_mul(hipStream_t s, const uint16_t* gate_up, int64_t T, int inter, uint16_t* out);
+
+// ---- k_rope_kv.hip ----------------------------------------------------------------------------
+hipError_t launch_rope_kv_write(hipStream_t s, uint16_t* qkv, const float* cos_sin, const KvAddr& kv, int quant_bit,
+                                int quant_group, const int64_t* seq_starts, const int64_t* start_pos,
+                                const int64_t* cache_indices, int64_t max_pages, int64_t B, int64_t T, int H, int Hkv,
+                                int D);
+
+// ---- k_attn_decode.hip ------------------------------------------------------------------------
+// rows [0, nb) of the batch are single-token queries; q row of request b is qkv row seq_starts[b].
+// split > 1 uses `workspace` (fp32 [nb, H, split, D+2]).
+size_t attn_decode_workspace_bytes(int64_t nb, int H, int D, int split);
+hipError_t launch_attn_decode(hipStream_t s, const uint16_t* qkv, const KvAddr& kv, int quant_bit,
+                              const int64_t* seq_starts, const int64_t* start_pos, const int64_t* cache_indices,
+                              int64_t max_pages, int64_t nb, int H, int Hkv, int D, int64_t max_kv_len, int split,
+                              int threads, float* workspace, uint16_t* out);
+
+// ---- k_attn_prefill.hip -----------------------------------------------------------------------
+// requests [b0, B): causal attention of their new tokens over the cache [0, start_pos + seqlen).
+hipError_t launch_attn_prefill(hipStream_t s, const uint16_t* qkv, const KvAddr& kv, int quant_bit,
+                               const int64_t* seq_starts, const int64_t* start_pos, const int64_t* cache_indices,
+                               int64_t max_pages, int64_t b0, int64_t B, int H, int Hkv, int D, int64_t max_seq_len,
+                               uint16_t* out);
+
+// ---- k_gemm.hip -------------------------------------------------------------------------------
+// y[M,N] = x[M,K] . W[N,K]^T (+ per-channel / per-group scales).  wq_bit 0/8/4.  out_fp32: y is float.
+// ldy = row stride of y in elements.
+hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const uint16_t* scale, int wq_bit, int group,
+                         int64_t M, int N, int K, void* y, int64_t ldy, bool out_fp32);
+
+// ---- k_sample.hip -----------------------------------------------------------------------------
+hipError_t launch_sample_greedy(hipStream_t s, const float* logits, const float* temperatures, int batch, int vocab,
+                                int stride, int32_t* out_tok, float* out_logprob);
+size_t sample_topk_workspace_bytes(int batch, int vocab, int top_k);
+hipError_t launch_sample_topk_topp(hipStream_t s, const float* logits, const float* temperatures, const float* top_p,
+                                   const float* rnd, int batch, int vocab, int stride, int top_k, float default_top_p,
+                                   void* workspace, int32_t* out_tok, float* out_logprob);
+hipError_t launch_penalty(hipStream_t s, float* logits, const float* temperatures, const float* rep,
+                          const float* presence, const float* frequency, const int64_t* batch_slots,
+                          const int64_t* token_inputs, const int64_t* seq_starts, const int64_t* start_pos, int batch,
+                          int vocab, int stride, uint16_t* count_map);
+
+// ---- synth.hip --------------------------------------------------------------------------------
+// kinds as in oracle/llama_ref.c: 0 fp16 uniform(-amp,amp), 1 int8, 2 packed int4 (n bytes), 3 scale, 4 norm
+hipError_t launch_synth_fill(hipStream_t s, int kind, uint64_t seed, uint32_t tensor_id, uint32_t stream_id, float amp,
+                             uint64_t n, void* out);
+
+}  // namespace pplhip

@@ -1,0 +1,909 @@
+// libpplhip.so -- the C ABI of include/pplhip.h: per-rank runtime (streams, weights, KV slab, step inputs,
+// activations), the decoder forward as a sequence of hand-written gfx950 kernels, RCCL collectives for tensor
+// parallelism and the sampler.  This file replaces what the reference reaches through ppl.nn
+// (Engine/Runtime/Tensor, src/backends/cuda/resource_manager.cc:43-211) and ppl.llm.kernel.cuda.
+#include "../../include/pplhip.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace pplhip;
+
+namespace {
+
+struct Linear {
+    int N = 0, K = 0, qbit = 0, group = 0;
+    void* w = nullptr;
+    uint16_t* scale = nullptr;
+    uint64_t w_bytes() const { return qbit == 0 ? (uint64_t)N * K * 2 : qbit == 8 ? (uint64_t)N * K : (uint64_t)N * K / 2; }
+    uint64_t s_bytes() const { return qbit == 0 ? 0 : qbit == 8 ? (uint64_t)N * 2 : (uint64_t)N * (K / group) * 2; }
+};
+
+struct Layer {
+    uint16_t* attn_norm = nullptr;
+    uint16_t* ffn_norm = nullptr;
+    Linear wqkv, wo, w13, w2;
+};
+
+struct ProfEvent {
+    int cls;
+    hipEvent_t a, b;
+};
+
+struct Rank {
+    int device = 0;
+    int global_rank = 0;
+    hipStream_t stream = nullptr;
+    ncclComm_t comm = nullptr;
+    std::string err;
+
+    // weights
+    uint16_t* embed = nullptr;
+    uint16_t* norm = nullptr;
+    Linear output;
+    std::vector<Layer> layers;
+    float* rope = nullptr;
+    std::vector<void*> allocs;
+
+    // KV slab
+    uint64_t kv_tokens = 0;
+    void* kv_cache = nullptr;
+    uint16_t* kv_scale = nullptr;
+
+    // step inputs
+    int64_t* stage_host[2] = {nullptr, nullptr};
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    int stage_cur = 0;
+    int64_t* step_dev = nullptr;  // packed: token_ids | seq_starts | kv_starts | start_pos | cache_indices(mode 0)
+    int64_t cap_T = 0, cap_B = 0;
+    int64_t *d_tok = nullptr, *d_seq = nullptr, *d_kvs = nullptr, *d_sp = nullptr, *d_ci = nullptr;
+    int64_t* pages_dev = nullptr;   // mode 1: [B, max_pages]
+    int64_t* pages_host = nullptr;  // pinned
+    uint64_t pages_cap = 0;
+    int64_t B = 0, T = 0, decoding_batches = 0, max_seq_len = 0, max_kv_len = 0, max_pages = 0;
+
+    // activations
+    uint16_t *h = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *part = nullptr, *part2 = nullptr, *gu = nullptr,
+             *act = nullptr, *hn = nullptr;
+    float* logits_local = nullptr;  // [B, V/tp] (tp > 1)
+    float* logits_gather = nullptr; // [tp, B, V/tp]
+    float* logits = nullptr;        // [B, V]
+    float* attn_ws = nullptr;
+    size_t attn_ws_bytes = 0;
+
+    // sampler (local rank 0)
+    float *d_temp = nullptr, *d_topp = nullptr, *d_rand = nullptr, *d_lp = nullptr;
+    int32_t* d_tokout = nullptr;
+    uint16_t* count_map = nullptr;
+    int64_t* d_slots = nullptr;
+    float *d_rep = nullptr, *d_pres = nullptr, *d_freq = nullptr, *d_ptemp = nullptr;
+    float* h_rand = nullptr;  // pinned
+
+    // profiling
+    std::vector<ProfEvent> prof;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_free;
+};
+
+}  // namespace
+
+struct pplhip_ctx {
+    pplhip_model_desc d;
+    pplhip_opts o;
+    int tp = 1;
+    int H = 0, Hkv = 0, D = 0, inter = 0, vocab_local = 0;
+    std::vector<Rank> ranks;
+    std::string err;
+};
+
+namespace {
+
+int fail(pplhip_ctx* c, int rank, int code, const std::string& msg) {
+    if (c) {
+        if (rank >= 0 && rank < (int)c->ranks.size()) c->ranks[rank].err = msg; else c->err = msg;
+    }
+    if (getenv("PPLHIP_VERBOSE")) fprintf(stderr, "[pplhip] error %d (rank %d): %s\n", code, rank, msg.c_str());
+    return code;
+}
+
+#define HIPCK(c, r, expr)                                                                                            \
+    do {                                                                                                             \
+        hipError_t e__ = (expr);                                                                                     \
+        if (e__ != hipSuccess)                                                                                       \
+            return fail(c, r, e__ == hipErrorOutOfMemory ? PPLHIP_OUT_OF_MEMORY : PPLHIP_DEVICE_RUNTIME_ERROR,       \
+                        std::string(#expr) + ": " + hipGetErrorString(e__));                                         \
+    } while (0)
+
+#define NCCLCK(c, r, expr)                                                                                           \
+    do {                                                                                                             \
+        ncclResult_t e__ = (expr);                                                                                   \
+        if (e__ != ncclSuccess)                                                                                      \
+            return fail(c, r, PPLHIP_DEVICE_RUNTIME_ERROR, std::string(#expr) + ": " + ncclGetErrorString(e__));     \
+    } while (0)
+
+int dev_alloc(pplhip_ctx* c, int r, void** p, uint64_t bytes) {
+    *p = nullptr;
+    if (bytes == 0) return 0;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return fail(c, r, PPLHIP_OUT_OF_MEMORY, "hipMalloc(" + std::to_string(bytes) + "): " + hipGetErrorString(e));
+    c->ranks[r].allocs.push_back(*p);
+    return 0;
+}
+
+int linear_alloc(pplhip_ctx* c, int r, Linear* l, int N, int K, int qbit, int group) {
+    l->N = N; l->K = K; l->qbit = qbit; l->group = group;
+    int rc = dev_alloc(c, r, &l->w, l->w_bytes());
+    if (rc) return rc;
+    return dev_alloc(c, r, (void**)&l->scale, l->s_bytes());
+}
+
+// name -> device buffer of a rank's slice; names: DESIGN.md "weight container"
+bool find_tensor(pplhip_ctx* c, Rank& R, const char* name, void** ptr, uint64_t* bytes) {
+    const int hd = c->d.hidden_dim;
+    if (!strcmp(name, "tok_embeddings.weight")) { *ptr = R.embed; *bytes = (uint64_t)c->d.vocab_size * hd * 2; return true; }
+    if (!strcmp(name, "norm.weight")) { *ptr = R.norm; *bytes = (uint64_t)hd * 2; return true; }
+    if (!strcmp(name, "output.weight")) { *ptr = R.output.w; *bytes = R.output.w_bytes(); return true; }
+    int l = -1;
+    char rest[128];
+    if (sscanf(name, "layers.%d.%127s", &l, rest) != 2 || l < 0 || l >= c->d.num_layers) return false;
+    Layer& L = R.layers[l];
+    if (!strcmp(rest, "attention_norm.weight")) { *ptr = L.attn_norm; *bytes = (uint64_t)hd * 2; return true; }
+    if (!strcmp(rest, "ffn_norm.weight")) { *ptr = L.ffn_norm; *bytes = (uint64_t)hd * 2; return true; }
+    struct { const char* n; Linear* lin; } tab[] = {{"attention.wqkv", &L.wqkv}, {"attention.wo", &L.wo},
+                                                      {"feed_forward.w13", &L.w13}, {"feed_forward.w2", &L.w2}};
+    for (auto& t : tab) {
+        const size_t nl = strlen(t.n);
+        if (strncmp(rest, t.n, nl)) continue;
+        if (!strcmp(rest + nl, ".weight")) { *ptr = t.lin->w; *bytes = t.lin->w_bytes(); return true; }
+        if (!strcmp(rest + nl, ".scale") && t.lin->qbit) { *ptr = t.lin->scale; *bytes = t.lin->s_bytes(); return true; }
+    }
+    return false;
+}
+
+KvAddr make_kv_addr(const pplhip_model_desc& d, int Hkv, int D, uint64_t tokens, void* cache, uint16_t* scale, int layer) {
+    const int elt = d.cache_quant_bit == 8 ? 1 : 2;
+    const int g = d.cache_quant_group > 0 ? d.cache_quant_group : 1;
+    const KvStrides cs = kv_strides(d.cache_layout, (int64_t)tokens, d.num_layers, Hkv, D);
+    const KvStrides ss = kv_strides(d.cache_layout, (int64_t)tokens, d.num_layers, Hkv, D / g);
+    KvAddr a;
+    a.cache = (char*)cache + (int64_t)layer * cs.sL * elt;
+    a.scale = scale ? scale + (int64_t)layer * ss.sL : nullptr;
+    a.sKV = cs.sKV; a.sH = cs.sH; a.sN = cs.sN;
+    a.ssKV = ss.sKV; a.ssH = ss.sH; a.ssN = ss.sN;
+    a.mode = d.cache_mode;
+    a.page_size = d.page_size > 0 ? d.page_size : 1;
+    return a;
+}
+
+void prof_begin(pplhip_ctx* c, Rank& R, int cls, ProfEvent* ev) {
+    ev->cls = -1;
+    if (!c->o.enable_profiling) return;
+    std::pair<hipEvent_t, hipEvent_t> p;
+    if (!R.prof_free.empty()) { p = R.prof_free.back(); R.prof_free.pop_back(); }
+    else { hipEventCreate(&p.first); hipEventCreate(&p.second); }
+    ev->cls = cls; ev->a = p.first; ev->b = p.second;
+    hipEventRecord(ev->a, R.stream);
+}
+void prof_end(Rank& R, ProfEvent* ev) {
+    if (ev->cls < 0) return;
+    hipEventRecord(ev->b, R.stream);
+    R.prof.push_back(*ev);
+}
+
+int decode_split(const pplhip_ctx* c, int64_t nb, int64_t max_kv_len) {
+    const int mode = c->o.decoding_attn_split_k;
+    if (mode == 0) return 1;
+    const int64_t blocks = nb * c->H;
+    int split = 1;
+    if (mode == 2 || (blocks < 1024 && max_kv_len >= 1024)) {
+        int64_t want = (2048 + blocks - 1) / blocks;           // aim for >= 2048 workgroups
+        int64_t cap = std::max<int64_t>(1, max_kv_len / 256);  // >= 256 tokens per split
+        split = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want, cap), 32));
+        if (mode == 2 && split < 2 && max_kv_len >= 64) split = 2;
+    }
+    return split;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pplhip_version(void) { return (1 << 16) | 0; }
+
+int pplhip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return PPLHIP_DEVICE_RUNTIME_ERROR;
+    return n;
+}
+
+int pplhip_get_unique_id(void* out) {
+    static_assert(sizeof(ncclUniqueId) <= PPLHIP_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return PPLHIP_DEVICE_RUNTIME_ERROR;
+    memset(out, 0, PPLHIP_UNIQUE_ID_BYTES);
+    memcpy(out, &id, sizeof(id));
+    return 0;
+}
+
+int pplhip_build_rope_table(float* out, int32_t max_position, int32_t head_dim, float theta) {
+    const int half = head_dim / 2;
+    for (int p = 0; p < max_position; ++p)
+        for (int i = 0; i < half; ++i) {
+            const double freq = pow((double)theta, -2.0 * (double)i / (double)head_dim);
+            const double a = (double)p * freq;
+            out[(size_t)p * head_dim + i] = (float)cos(a);
+            out[(size_t)p * head_dim + half + i] = (float)sin(a);
+        }
+    return 0;
+}
+
+void pplhip_destroy(pplhip_ctx* c) {
+    if (!c) return;
+    for (auto& R : c->ranks) {
+        hipSetDevice(R.device);
+        if (R.stream) hipStreamSynchronize(R.stream);
+        if (R.comm) ncclCommDestroy(R.comm);
+        for (auto& e : R.prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+        for (auto& p : R.prof_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+        for (void* p : R.allocs) hipFree(p);
+        if (R.kv_cache) hipFree(R.kv_cache);
+        if (R.kv_scale) hipFree(R.kv_scale);
+        for (int i = 0; i < 2; ++i) {
+            if (R.stage_host[i]) hipHostFree(R.stage_host[i]);
+            if (R.stage_ev[i]) hipEventDestroy(R.stage_ev[i]);
+        }
+        if (R.pages_host) hipHostFree(R.pages_host);
+        if (R.pages_dev) hipFree(R.pages_dev);
+        if (R.h_rand) hipHostFree(R.h_rand);
+        if (R.stream) hipStreamDestroy(R.stream);
+    }
+    delete c;
+}
+
+const char* pplhip_last_error(pplhip_ctx* c, int rank) {
+    if (!c) return "null context";
+    if (rank >= 0 && rank < (int)c->ranks.size() && !c->ranks[rank].err.empty()) return c->ranks[rank].err.c_str();
+    return c->err.c_str();
+}
+
+int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_ctx** out) {
+    if (!desc || !opts || !out) return PPLHIP_INVALID_VALUE;
+    *out = nullptr;
+    std::unique_ptr<pplhip_ctx> c(new pplhip_ctx());
+    c->d = *desc;
+    c->o = *opts;
+    c->o.device_ids = nullptr;
+    c->o.nccl_unique_id = nullptr;
+    const int n = opts->n_local_ranks;
+    const int tp = opts->world_size > 0 ? opts->world_size : n;
+    c->tp = tp;
+    const pplhip_model_desc& d = c->d;
+    auto bad = [&](const char* m) { if (getenv("PPLHIP_VERBOSE")) fprintf(stderr, "[pplhip] init: %s\n", m); return PPLHIP_INVALID_VALUE; };
+    if (n < 1 || tp < n || opts->rank_base < 0 || opts->rank_base + n > tp) return bad("rank layout");
+    if (d.num_heads <= 0 || d.hidden_dim % d.num_heads) return bad("heads");
+    if (d.num_heads % tp || d.num_kv_heads % tp || d.intermediate_dim % tp || d.vocab_size % tp) return bad("tp divisibility");
+    if (d.num_heads % d.num_kv_heads) return bad("gqa");
+    // src/generator/llm_generator.cc:114-144 (CheckParameters)
+    if (!((d.cache_quant_bit == 8 && d.cache_quant_group == 8) || (d.cache_quant_bit == 0 && d.cache_quant_group == 1))) return bad("cache quant");
+    if (d.cache_layout < 0 || d.cache_layout > 3 || d.cache_mode < 0 || d.cache_mode > 1) return bad("cache layout/mode");
+    if (d.cache_mode == 1 && d.page_size <= 0) return bad("page_size");
+    if (d.weight_quant_bit != 0 && d.weight_quant_bit != 8 && d.weight_quant_bit != 4) return bad("weight quant");
+    if (opts->max_running_batch <= 0 || opts->max_tokens_per_step <= 0 || d.max_position <= 0) return bad("limits");
+    c->D = d.hidden_dim / d.num_heads;
+    c->H = d.num_heads / tp;
+    c->Hkv = d.num_kv_heads / tp;
+    c->inter = d.intermediate_dim / tp;
+    c->vocab_local = d.vocab_size / tp;
+    if (c->D != 32 && c->D != 64 && c->D != 128) return bad("head_dim must be 32, 64 or 128");
+    if (d.hidden_dim % 16 || c->inter % 16 || c->vocab_local % 4) return bad("dims alignment");
+    if (d.weight_quant_bit == 4 && (d.weight_quant_group % 32 || d.hidden_dim % d.weight_quant_group ||
+                                    (c->H * c->D) % d.weight_quant_group || c->inter % d.weight_quant_group)) return bad("w4 group");
+
+    c->ranks.resize(n);
+    pplhip_ctx* cp = c.get();
+    std::vector<int> devs(n);
+    for (int r = 0; r < n; ++r) devs[r] = opts->device_ids ? opts->device_ids[r] : r;
+
+    // communicators (replaces ppl::common::InitNccl, resource_manager.cc:393)
+    if (tp > 1) {
+        std::vector<ncclComm_t> comms(n);
+        if (tp == n) {
+            NCCLCK(cp, -1, ncclCommInitAll(comms.data(), n, devs.data()));
+        } else {
+            if (!opts->nccl_unique_id) return fail(cp, -1, PPLHIP_INVALID_VALUE, "nccl_unique_id required when world_size > n_local_ranks");
+            ncclUniqueId id;
+            memcpy(&id, opts->nccl_unique_id, sizeof(id));
+            NCCLCK(cp, -1, ncclGroupStart());
+            for (int r = 0; r < n; ++r) {
+                HIPCK(cp, -1, hipSetDevice(devs[r]));
+                NCCLCK(cp, -1, ncclCommInitRank(&comms[r], tp, id, opts->rank_base + r));
+            }
+            NCCLCK(cp, -1, ncclGroupEnd());
+        }
+        for (int r = 0; r < n; ++r) c->ranks[r].comm = comms[r];
+    }
+
+    const int64_t cap_B = opts->max_running_batch;
+    const int64_t cap_T = std::max<int64_t>(opts->max_tokens_per_step, opts->max_running_batch);
+    const int hd = d.hidden_dim, q = d.weight_quant_bit, g = d.weight_quant_group;
+    std::vector<float> rope((size_t)d.max_position * c->D);
+    pplhip_build_rope_table(rope.data(), d.max_position, c->D, d.rope_theta);
+
+    for (int r = 0; r < n; ++r) {
+        Rank& R = c->ranks[r];
+        R.device = devs[r];
+        R.global_rank = opts->rank_base + r;
+        HIPCK(cp, r, hipSetDevice(R.device));
+        HIPCK(cp, r, hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
+        int rc;
+#define ALLOC(ptr, bytes) if ((rc = dev_alloc(cp, r, (void**)&(ptr), (uint64_t)(bytes)))) return rc
+        ALLOC(R.embed, (uint64_t)d.vocab_size * hd * 2);
+        ALLOC(R.norm, hd * 2);
+        if ((rc = linear_alloc(cp, r, &R.output, c->vocab_local, hd, 0, 0))) return rc;
+        R.layers.resize(d.num_layers);
+        for (int l = 0; l < d.num_layers; ++l) {
+            Layer& L = R.layers[l];
+            ALLOC(L.attn_norm, hd * 2);
+            ALLOC(L.ffn_norm, hd * 2);
+            if ((rc = linear_alloc(cp, r, &L.wqkv, (c->H + 2 * c->Hkv) * c->D, hd, q, g))) return rc;
+            if ((rc = linear_alloc(cp, r, &L.wo, hd, c->H * c->D, q, g))) return rc;
+            if ((rc = linear_alloc(cp, r, &L.w13, 2 * c->inter, hd, q, g))) return rc;
+            if ((rc = linear_alloc(cp, r, &L.w2, hd, c->inter, q, g))) return rc;
+        }
+        ALLOC(R.rope, rope.size() * sizeof(float));
+        HIPCK(cp, r, hipMemcpy(R.rope, rope.data(), rope.size() * sizeof(float), hipMemcpyHostToDevice));
+
+        // step inputs
+        R.cap_B = cap_B; R.cap_T = cap_T;
+        const uint64_t step_elems = (uint64_t)cap_T + 4 * (cap_B + 1);
+        for (int i = 0; i < 2; ++i) {
+            HIPCK(cp, r, hipHostMalloc((void**)&R.stage_host[i], step_elems * 8, hipHostMallocDefault));
+            HIPCK(cp, r, hipEventCreateWithFlags(&R.stage_ev[i], hipEventDisableTiming));
+        }
+        ALLOC(R.step_dev, step_elems * 8);
+
+        // activations
+        ALLOC(R.h, (uint64_t)cap_T * hd * 2);
+        ALLOC(R.xn, (uint64_t)cap_T * hd * 2);
+        ALLOC(R.qkv, (uint64_t)cap_T * (c->H + 2 * c->Hkv) * c->D * 2);
+        ALLOC(R.att, (uint64_t)cap_T * c->H * c->D * 2);
+        ALLOC(R.part, (uint64_t)cap_T * hd * 2);
+        ALLOC(R.part2, (uint64_t)cap_T * hd * 2);
+        ALLOC(R.gu, (uint64_t)cap_T * 2 * c->inter * 2);
+        ALLOC(R.act, (uint64_t)cap_T * c->inter * 2);
+        ALLOC(R.hn, (uint64_t)cap_B * hd * 2);
+        ALLOC(R.logits, (uint64_t)cap_B * d.vocab_size * 4);
+        if (tp > 1) {
+            ALLOC(R.logits_local, (uint64_t)cap_B * c->vocab_local * 4);
+            ALLOC(R.logits_gather, (uint64_t)cap_B * d.vocab_size * 4);
+        }
+        R.attn_ws_bytes = attn_decode_workspace_bytes(cap_B, c->H, c->D, 32);
+        ALLOC(R.attn_ws, R.attn_ws_bytes);
+
+        if (r == 0) {  // sampler lives on local rank 0 (src/backends/cuda/resource_manager.cc:315-327)
+            ALLOC(R.d_temp, cap_B * 4); ALLOC(R.d_topp, cap_B * 4); ALLOC(R.d_rand, cap_B * 4);
+            ALLOC(R.d_lp, cap_B * 4); ALLOC(R.d_tokout, cap_B * 4);
+            HIPCK(cp, r, hipHostMalloc((void**)&R.h_rand, cap_B * 4, hipHostMallocDefault));
+            if (opts->enable_penalty) {
+                ALLOC(R.count_map, (uint64_t)cap_B * d.vocab_size * 2);
+                ALLOC(R.d_slots, cap_B * 8);
+                ALLOC(R.d_rep, cap_B * 4); ALLOC(R.d_pres, cap_B * 4); ALLOC(R.d_freq, cap_B * 4); ALLOC(R.d_ptemp, cap_B * 4);
+                HIPCK(cp, r, hipMemset(R.count_map, 0, (uint64_t)cap_B * d.vocab_size * 2));
+            }
+        }
+#undef ALLOC
+        HIPCK(cp, r, hipDeviceSynchronize());
+    }
+    *out = c.release();
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ weights */
+
+int pplhip_rank_set_tensor(pplhip_ctx* c, int rank, const char* name, const void* data, uint64_t bytes) {
+    if (!c || rank < 0 || rank >= (int)c->ranks.size() || !name || !data) return PPLHIP_INVALID_VALUE;
+    Rank& R = c->ranks[rank];
+    void* p; uint64_t b;
+    if (!find_tensor(c, R, name, &p, &b)) return fail(c, rank, PPLHIP_NOT_FOUND, std::string("unknown tensor ") + name);
+    if (b != bytes) return fail(c, rank, PPLHIP_INVALID_VALUE, std::string("tensor ") + name + ": got " + std::to_string(bytes) + " bytes, want " + std::to_string(b));
+    HIPCK(c, rank, hipSetDevice(R.device));
+    HIPCK(c, rank, hipMemcpy(p, data, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// container: "PPLHIPW1" | u32 count | count x { u32 name_len | name | u64 nbytes | pad to 64 | data }
+int pplhip_rank_load(pplhip_ctx* c, int rank, const char* slice_dir) {
+    if (!c || rank < 0 || rank >= (int)c->ranks.size() || !slice_dir) return PPLHIP_INVALID_VALUE;
+    const std::string path = std::string(slice_dir) + "/weights.pplhip";
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return fail(c, rank, PPLHIP_NOT_FOUND, "cannot open " + path);
+    char magic[8];
+    uint32_t count = 0;
+    int rc = 0;
+    std::vector<char> buf;
+    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "PPLHIPW1", 8) || fread(&count, 4, 1, f) != 1) {
+        fclose(f);
+        return fail(c, rank, PPLHIP_INVALID_VALUE, "bad header in " + path);
+    }
+    for (uint32_t i = 0; i < count && !rc; ++i) {
+        uint32_t nl = 0; uint64_t nb = 0;
+        char name[256];
+        if (fread(&nl, 4, 1, f) != 1 || nl >= sizeof(name) || fread(name, 1, nl, f) != nl || fread(&nb, 8, 1, f) != 1) { rc = PPLHIP_INVALID_VALUE; break; }
+        name[nl] = 0;
+        long pos = ftell(f);
+        long pad = (64 - pos % 64) % 64;
+        fseek(f, pad, SEEK_CUR);
+        buf.resize(nb);
+        if (fread(buf.data(), 1, nb, f) != nb) { rc = PPLHIP_INVALID_VALUE; break; }
+        rc = pplhip_rank_set_tensor(c, rank, name, buf.data(), nb);
+    }
+    fclose(f);
+    if (rc == PPLHIP_INVALID_VALUE && c->ranks[rank].err.empty()) fail(c, rank, rc, "truncated container " + path);
+    return rc;
+}
+
+int pplhip_rank_init_synthetic(pplhip_ctx* c, int rank, uint64_t seed) {
+    if (!c || rank < 0 || rank >= (int)c->ranks.size()) return PPLHIP_INVALID_VALUE;
+    Rank& R = c->ranks[rank];
+    HIPCK(c, rank, hipSetDevice(R.device));
+    const int hd = c->d.hidden_dim;
+    const uint32_t st = 1u + (uint32_t)R.global_rank;
+    const float AMP = 0.034641016f;
+    auto tid = [](int layer, int slot) { return (uint32_t)((layer + 1) * 32 + slot); };
+    hipStream_t s = R.stream;
+    auto lin = [&](Linear& l, int layer, int wslot) -> hipError_t {
+        hipError_t e;
+        if (l.qbit == 0) return launch_synth_fill(s, 0, seed, tid(layer, wslot), st, AMP, (uint64_t)l.N * l.K, l.w);
+        if (l.qbit == 8) {
+            if ((e = launch_synth_fill(s, 1, seed, tid(layer, wslot), st, 0.f, (uint64_t)l.N * l.K, l.w)) != hipSuccess) return e;
+            return launch_synth_fill(s, 3, seed, tid(layer, wslot + 1), st, AMP / 127.0f, (uint64_t)l.N, l.scale);
+        }
+        if ((e = launch_synth_fill(s, 2, seed, tid(layer, wslot), st, 0.f, (uint64_t)l.N * l.K / 2, l.w)) != hipSuccess) return e;
+        return launch_synth_fill(s, 3, seed, tid(layer, wslot + 1), st, AMP / 7.0f, (uint64_t)l.N * (l.K / l.group), l.scale);
+    };
+    HIPCK(c, rank, launch_synth_fill(s, 0, seed, tid(-1, 0), 0, 1.0f, (uint64_t)c->d.vocab_size * hd, R.embed));
+    HIPCK(c, rank, launch_synth_fill(s, 4, seed, tid(-1, 11), 0, 0.f, hd, R.norm));
+    HIPCK(c, rank, launch_synth_fill(s, 0, seed, tid(-1, 12), st, AMP, (uint64_t)c->vocab_local * hd, R.output.w));
+    for (int l = 0; l < c->d.num_layers; ++l) {
+        Layer& L = R.layers[l];
+        HIPCK(c, rank, launch_synth_fill(s, 4, seed, tid(l, 1), 0, 0.f, hd, L.attn_norm));
+        HIPCK(c, rank, launch_synth_fill(s, 4, seed, tid(l, 6), 0, 0.f, hd, L.ffn_norm));
+        HIPCK(c, rank, lin(L.wqkv, l, 2));
+        HIPCK(c, rank, lin(L.wo, l, 4));
+        HIPCK(c, rank, lin(L.w13, l, 7));
+        HIPCK(c, rank, lin(L.w2, l, 9));
+    }
+    HIPCK(c, rank, hipStreamSynchronize(s));
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ KV slab */
+
+int pplhip_kv_block_bytes(pplhip_ctx* c, uint64_t* cache_bytes, uint64_t* scale_bytes) {
+    if (!c) return PPLHIP_INVALID_VALUE;
+    // src/backends/cuda/resource_manager.cc:381-387
+    const uint64_t elt = c->d.cache_quant_bit == 8 ? 1 : 2;
+    const uint64_t kb = (uint64_t)c->d.num_layers * 2 * c->Hkv * c->D * elt;
+    const uint64_t sb = c->d.cache_quant_bit > 0 ? (uint64_t)c->d.num_layers * 2 * c->Hkv * (c->D / c->d.cache_quant_group) * 2 : 0;
+    if (cache_bytes) *cache_bytes = kb;
+    if (scale_bytes) *scale_bytes = sb;
+    return 0;
+}
+
+int pplhip_kv_capacity(pplhip_ctx* c, float max_tokens_scale, uint64_t* tokens) {
+    if (!c || !tokens) return PPLHIP_INVALID_VALUE;
+    uint64_t kb, sb;
+    pplhip_kv_block_bytes(c, &kb, &sb);
+    HIPCK(c, 0, hipSetDevice(c->ranks[0].device));
+    size_t free_b = 0, total = 0;
+    HIPCK(c, 0, hipMemGetInfo(&free_b, &total));
+    // resource_manager.cc:330-341
+    const uint64_t kv_cache_max_bytes = (uint64_t)((double)max_tokens_scale * (double)free_b * (double)kb / (double)(kb + sb));
+    *tokens = kv_cache_max_bytes / kb;
+    return 0;
+}
+
+int pplhip_kv_alloc(pplhip_ctx* c, int rank, uint64_t tokens) {
+    if (!c || rank < 0 || rank >= (int)c->ranks.size() || tokens == 0) return PPLHIP_INVALID_VALUE;
+    Rank& R = c->ranks[rank];
+    HIPCK(c, rank, hipSetDevice(R.device));
+    uint64_t kb, sb;
+    pplhip_kv_block_bytes(c, &kb, &sb);
+    if (R.kv_cache) { hipFree(R.kv_cache); R.kv_cache = nullptr; }
+    if (R.kv_scale) { hipFree(R.kv_scale); R.kv_scale = nullptr; }
+    hipError_t e = hipMalloc(&R.kv_cache, tokens * kb);
+    if (e != hipSuccess) return fail(c, rank, PPLHIP_OUT_OF_MEMORY, "alloc kv cache [" + std::to_string(tokens * kb) + "] failed: " + hipGetErrorString(e));
+    if (sb) {
+        e = hipMalloc((void**)&R.kv_scale, tokens * sb);
+        if (e != hipSuccess) {
+            hipFree(R.kv_cache); R.kv_cache = nullptr;
+            return fail(c, rank, PPLHIP_OUT_OF_MEMORY, "alloc kv scale [" + std::to_string(tokens * sb) + "] failed: " + hipGetErrorString(e));
+        }
+    }
+    R.kv_tokens = tokens;
+    return 0;
+}
+
+int pplhip_kv_ptrs(pplhip_ctx* c, int rank, void** kv_cache_mem, void** kv_scale_mem) {
+    if (!c || rank < 0 || rank >= (int)c->ranks.size()) return PPLHIP_INVALID_VALUE;
+    if (kv_cache_mem) *kv_cache_mem = c->ranks[rank].kv_cache;
+    if (kv_scale_mem) *kv_scale_mem = c->ranks[rank].kv_scale;
+    return 0;
+}
+
+static int kv_rw(pplhip_ctx* c, int rank, int which, uint64_t offset, void* host, uint64_t bytes, bool read) {
+    if (!c || rank < 0 || rank >= (int)c->ranks.size() || !host) return PPLHIP_INVALID_VALUE;
+    Rank& R = c->ranks[rank];
+    uint64_t kb, sb;
+    pplhip_kv_block_bytes(c, &kb, &sb);
+    char* base = which ? (char*)R.kv_scale : (char*)R.kv_cache;
+    const uint64_t total = R.kv_tokens * (which ? sb : kb);
+    if (!base || offset + bytes > total) return fail(c, rank, PPLHIP_INVALID_VALUE, "kv read/write out of range");
+    HIPCK(c, rank, hipSetDevice(R.device));
+    HIPCK(c, rank, hipStreamSynchronize(R.stream));
+    if (read) HIPCK(c, rank, hipMemcpy(host, base + offset, bytes, hipMemcpyDeviceToHost));
+    else HIPCK(c, rank, hipMemcpy(base + offset, host, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+int pplhip_kv_read(pplhip_ctx* c, int rank, int which, uint64_t offset, void* dst, uint64_t bytes) {
+    return kv_rw(c, rank, which, offset, dst, bytes, true);
+}
+int pplhip_kv_write(pplhip_ctx* c, int rank, int which, uint64_t offset, const void* src, uint64_t bytes) {
+    return kv_rw(c, rank, which, offset, const_cast<void*>(src), bytes, false);
+}
+
+int pplhip_kv_fill_synthetic(pplhip_ctx* c, int rank, uint64_t seed) {
+    if (!c || rank < 0 || rank >= (int)c->ranks.size()) return PPLHIP_INVALID_VALUE;
+    Rank& R = c->ranks[rank];
+    if (!R.kv_cache) return fail(c, rank, PPLHIP_INVALID_VALUE, "kv slab not allocated");
+    HIPCK(c, rank, hipSetDevice(R.device));
+    uint64_t kb, sb;
+    pplhip_kv_block_bytes(c, &kb, &sb);
+    const uint32_t st = 100u + (uint32_t)R.global_rank;
+    if (c->d.cache_quant_bit == 8) {
+        HIPCK(c, rank, launch_synth_fill(R.stream, 1, seed, 1, st, 0.f, R.kv_tokens * kb, R.kv_cache));
+        HIPCK(c, rank, launch_synth_fill(R.stream, 3, seed, 2, st, 0.02f, R.kv_tokens * sb / 2, R.kv_scale));
+    } else {
+        HIPCK(c, rank, launch_synth_fill(R.stream, 0, seed, 1, st, 1.5f, R.kv_tokens * kb / 2, R.kv_cache));
+    }
+    HIPCK(c, rank, hipStreamSynchronize(R.stream));
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ the step */
+
+int pplhip_set_inputs(pplhip_ctx* c, int rank, const pplhip_step* st) {
+    if (!c || rank < 0 || rank >= (int)c->ranks.size() || !st) return PPLHIP_INVALID_VALUE;
+    Rank& R = c->ranks[rank];
+    const int64_t B = st->batch, T = st->num_tokens;
+    if (B < 0 || T < 0 || B > R.cap_B || T > R.cap_T)
+        return fail(c, rank, PPLHIP_INVALID_VALUE, "step exceeds max_running_batch / max_tokens_per_step");
+    if (B > 0 && (!st->token_inputs || !st->seq_starts || !st->kv_starts || !st->start_pos)) return PPLHIP_INVALID_VALUE;
+    if (st->max_kv_len > c->d.max_position) return fail(c, rank, PPLHIP_INVALID_VALUE, "max_kv_len exceeds max_position");
+    HIPCK(c, rank, hipSetDevice(R.device));
+    const int cur = R.stage_cur;
+    R.stage_cur ^= 1;
+    HIPCK(c, rank, hipEventSynchronize(R.stage_ev[cur]));  // the copy that last used this staging buffer is done
+    int64_t* hbuf = R.stage_host[cur];
+    // packed layout: token_ids[T] | seq_starts[B+1] | kv_starts[B+1] | start_pos[B] | cache_indices[B] (mode 0)
+    int64_t off = 0;
+    memcpy(hbuf + off, st->token_inputs, T * 8); R.d_tok = R.step_dev + off; off += T;
+    memcpy(hbuf + off, st->seq_starts, (B + 1) * 8); R.d_seq = R.step_dev + off; off += B + 1;
+    memcpy(hbuf + off, st->kv_starts, (B + 1) * 8); R.d_kvs = R.step_dev + off; off += B + 1;
+    memcpy(hbuf + off, st->start_pos, B * 8); R.d_sp = R.step_dev + off; off += B;
+    if (c->d.cache_mode == 0) {
+        if (B > 0 && !st->cache_indices) return PPLHIP_INVALID_VALUE;
+        memcpy(hbuf + off, st->cache_indices, B * 8); R.d_ci = R.step_dev + off; off += B;
+    }
+    HIPCK(c, rank, hipMemcpyAsync(R.step_dev, hbuf, off * 8, hipMemcpyHostToDevice, R.stream));
+    HIPCK(c, rank, hipEventRecord(R.stage_ev[cur], R.stream));
+    if (c->d.cache_mode == 1 && st->req_list_changed) {  // src/engine/llm_engine.cc:67-71
+        if (!st->cache_indices || st->max_pages <= 0) return fail(c, rank, PPLHIP_INVALID_VALUE, "page list missing");
+        const uint64_t n = (uint64_t)B * st->max_pages;
+        if (n > R.pages_cap) {
+            HIPCK(c, rank, hipStreamSynchronize(R.stream));
+            if (R.pages_dev) hipFree(R.pages_dev);
+            if (R.pages_host) hipHostFree(R.pages_host);
+            R.pages_cap = std::max<uint64_t>(n * 2, 4096);
+            HIPCK(c, rank, hipMalloc((void**)&R.pages_dev, R.pages_cap * 8));
+            HIPCK(c, rank, hipHostMalloc((void**)&R.pages_host, R.pages_cap * 8, hipHostMallocDefault));
+        } else {
+            HIPCK(c, rank, hipStreamSynchronize(R.stream));  // previous async copy from pages_host
+        }
+        memcpy(R.pages_host, st->cache_indices, n * 8);
+        HIPCK(c, rank, hipMemcpyAsync(R.pages_dev, R.pages_host, n * 8, hipMemcpyHostToDevice, R.stream));
+        R.max_pages = st->max_pages;
+    }
+    if (c->d.cache_mode == 1) R.d_ci = R.pages_dev;
+    R.B = B; R.T = T;
+    R.decoding_batches = st->decoding_batches;
+    R.max_seq_len = st->max_seq_len;
+    R.max_kv_len = st->max_kv_len;
+    return 0;
+}
+
+static int attention_dispatch(pplhip_ctx* c, int rank, hipStream_t s, const uint16_t* qkv, const KvAddr& kv, int qbit,
+                              const int64_t* seq, const int64_t* sp, const int64_t* ci, int64_t max_pages, int64_t B,
+                              int64_t nb_decode, int64_t max_seq_len, int64_t max_kv_len, int H, int Hkv, int D, int split,
+                              int threads, float* ws, uint16_t* out, Rank* R) {
+    ProfEvent ev;
+    if (nb_decode > 0) {
+        if (R) prof_begin(c, *R, PPLHIP_PROF_ATTN_DECODE, &ev);
+        HIPCK(c, rank, launch_attn_decode(s, qkv, kv, qbit, seq, sp, ci, max_pages, nb_decode, H, Hkv, D, max_kv_len, split,
+                                          threads, ws, out));
+        if (R) prof_end(*R, &ev);
+    }
+    if (B > nb_decode) {
+        if (R) prof_begin(c, *R, PPLHIP_PROF_ATTN_PREFILL, &ev);
+        HIPCK(c, rank, launch_attn_prefill(s, qkv, kv, qbit, seq, sp, ci, max_pages, nb_decode, B, H, Hkv, D, max_seq_len, out));
+        if (R) prof_end(*R, &ev);
+    }
+    return 0;
+}
+
+int pplhip_run(pplhip_ctx* c, int rank, int cache_prefill) {
+    (void)cache_prefill;  // K6 and K7 are one kernel here: attention always reads K/V back from the slab
+    if (!c || rank < 0 || rank >= (int)c->ranks.size()) return PPLHIP_INVALID_VALUE;
+    Rank& R = c->ranks[rank];
+    const pplhip_model_desc& d = c->d;
+    if (!R.kv_cache) return fail(c, rank, PPLHIP_INVALID_VALUE, "kv slab not allocated");
+    HIPCK(c, rank, hipSetDevice(R.device));
+    hipStream_t s = R.stream;
+    const int64_t T = R.T, B = R.B;
+    if (B == 0) return 0;
+    const int hd = d.hidden_dim, H = c->H, Hkv = c->Hkv, D = c->D, inter = c->inter;
+    int64_t nb_decode = std::min<int64_t>(std::max<int64_t>(R.decoding_batches, 0), B);
+    const int split = nb_decode > 0 ? decode_split(c, nb_decode, R.max_kv_len) : 1;
+    const int threads = c->o.decoding_attn_tpb == 512 ? 512 : 256;
+    ProfEvent ev_run, ev;
+    prof_begin(c, R, PPLHIP_PROF_RUN, &ev_run);
+
+    HIPCK(c, rank, launch_embedding(s, R.d_tok, R.embed, T, hd, R.h));
+    const uint16_t* pending = nullptr;
+    for (int l = 0; l < d.num_layers; ++l) {
+        Layer& L = R.layers[l];
+        HIPCK(c, rank, launch_rmsnorm(s, R.h, pending, L.attn_norm, d.norm_eps, T, hd, nullptr, R.xn, pending ? R.h : nullptr));
+        prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
+        HIPCK(c, rank, launch_linear(s, R.xn, L.wqkv.w, L.wqkv.scale, L.wqkv.qbit, L.wqkv.group, T, L.wqkv.N, L.wqkv.K, R.qkv, L.wqkv.N, false));
+        prof_end(R, &ev);
+        const KvAddr kv = make_kv_addr(d, Hkv, D, R.kv_tokens, R.kv_cache, R.kv_scale, l);
+        HIPCK(c, rank, launch_rope_kv_write(s, R.qkv, R.rope, kv, d.cache_quant_bit, d.cache_quant_group, R.d_seq, R.d_sp,
+                                            R.d_ci, R.max_pages, B, T, H, Hkv, D));
+        int rc = attention_dispatch(c, rank, s, R.qkv, kv, d.cache_quant_bit, R.d_seq, R.d_sp, R.d_ci, R.max_pages, B,
+                                    nb_decode, R.max_seq_len, R.max_kv_len, H, Hkv, D, split, threads, R.attn_ws, R.att, &R);
+        if (rc) return rc;
+        prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
+        HIPCK(c, rank, launch_linear(s, R.att, L.wo.w, L.wo.scale, L.wo.qbit, L.wo.group, T, L.wo.N, L.wo.K, R.part, hd, false));
+        prof_end(R, &ev);
+        if (c->tp > 1) NCCLCK(c, rank, ncclAllReduce(R.part, R.part, (size_t)T * hd, ncclFloat16, ncclSum, R.comm, s));
+        HIPCK(c, rank, launch_rmsnorm(s, R.h, R.part, L.ffn_norm, d.norm_eps, T, hd, nullptr, R.xn, R.h));
+        prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
+        HIPCK(c, rank, launch_linear(s, R.xn, L.w13.w, L.w13.scale, L.w13.qbit, L.w13.group, T, L.w13.N, L.w13.K, R.gu, L.w13.N, false));
+        prof_end(R, &ev);
+        HIPCK(c, rank, launch_silu_mul(s, R.gu, T, inter, R.act));
+        prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
+        HIPCK(c, rank, launch_linear(s, R.act, L.w2.w, L.w2.scale, L.w2.qbit, L.w2.group, T, L.w2.N, L.w2.K, R.part2, hd, false));
+        prof_end(R, &ev);
+        if (c->tp > 1) NCCLCK(c, rank, ncclAllReduce(R.part2, R.part2, (size_t)T * hd, ncclFloat16, ncclSum, R.comm, s));
+        pending = R.part2;
+    }
+    // K11: last-token gather + final (Skip)RMSNorm + lm_head (+ all-gather of the vocab shards)
+    if (pending) {
+        // fold the last FFN output into the residual of the gathered rows only
+        HIPCK(c, rank, launch_rmsnorm(s, R.h, pending, R.norm, d.norm_eps, B, hd, R.d_seq, R.hn, nullptr));
+    } else {
+        HIPCK(c, rank, launch_rmsnorm(s, R.h, nullptr, R.norm, d.norm_eps, B, hd, R.d_seq, R.hn, nullptr));
+    }
+    prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
+    if (c->tp == 1) {
+        HIPCK(c, rank, launch_linear(s, R.hn, R.output.w, nullptr, 0, 0, B, R.output.N, hd, R.logits, d.vocab_size, true));
+        prof_end(R, &ev);
+    } else {
+        const int vl = c->vocab_local;
+        HIPCK(c, rank, launch_linear(s, R.hn, R.output.w, nullptr, 0, 0, B, vl, hd, R.logits_local, vl, true));
+        prof_end(R, &ev);
+        NCCLCK(c, rank, ncclAllGather(R.logits_local, R.logits_gather, (size_t)B * vl, ncclFloat32, R.comm, s));
+        for (int r = 0; r < c->tp; ++r)
+            HIPCK(c, rank, hipMemcpy2DAsync(R.logits + (size_t)r * vl, (size_t)d.vocab_size * 4, R.logits_gather + (size_t)r * B * vl,
+                                            (size_t)vl * 4, (size_t)vl * 4, B, hipMemcpyDeviceToDevice, s));
+    }
+    prof_end(R, &ev_run);
+    return 0;
+}
+
+int pplhip_logits(pplhip_ctx* c, int rank, float** logits_device, int64_t* stride) {
+    if (!c || rank < 0 || rank >= (int)c->ranks.size()) return PPLHIP_INVALID_VALUE;
+    if (logits_device) *logits_device = c->ranks[rank].logits;
+    if (stride) *stride = c->d.vocab_size;
+    return 0;
+}
+
+int pplhip_sync(pplhip_ctx* c, int rank) {
+    if (!c || rank < 0 || rank >= (int)c->ranks.size()) return PPLHIP_INVALID_VALUE;
+    HIPCK(c, rank, hipSetDevice(c->ranks[rank].device));
+    HIPCK(c, rank, hipStreamSynchronize(c->ranks[rank].stream));
+    return 0;
+}
+
+int pplhip_copy_logits(pplhip_ctx* c, int rank, float* dst, int64_t batch) {
+    if (!c || rank < 0 || rank >= (int)c->ranks.size() || !dst) return PPLHIP_INVALID_VALUE;
+    Rank& R = c->ranks[rank];
+    HIPCK(c, rank, hipSetDevice(R.device));
+    HIPCK(c, rank, hipStreamSynchronize(R.stream));
+    HIPCK(c, rank, hipMemcpy(dst, R.logits, (size_t)batch * c->d.vocab_size * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ sampler */
+
+int pplhip_sample(pplhip_ctx* c, const float* logits_device, const pplhip_sample_args* a, int32_t* output_host,
+                  float* logprob_host) {
+    if (!c || !a || !logits_device || !output_host || !logprob_host) return PPLHIP_INVALID_VALUE;
+    Rank& R = c->ranks[0];
+    const int B = a->batch;
+    if (B < 0 || B > R.cap_B) return fail(c, 0, PPLHIP_INVALID_VALUE, "batch exceeds max_running_batch");
+    HIPCK(c, 0, hipSetDevice(R.device));
+    hipStream_t s = R.stream;
+    // src/backends/cuda/post_processor.cc:126,154-177: temperatures are skipped when the penalty kernel already
+    // applied them; device copies are refreshed only when the batch changed and (quirk Q3 of SURVEY.md, kept)
+    // passed to the kernel only on those steps.
+    const float* temps_host = a->enable_penalty ? nullptr : a->temperatures;
+    const float* temp_opt = nullptr;
+    const float* topp_opt = nullptr;
+    if (a->req_list_changed) {
+        if (temps_host) { HIPCK(c, 0, hipMemcpyAsync(R.d_temp, temps_host, B * 4, hipMemcpyHostToDevice, s)); temp_opt = R.d_temp; }
+        if (a->top_p) { HIPCK(c, 0, hipMemcpyAsync(R.d_topp, a->top_p, B * 4, hipMemcpyHostToDevice, s)); topp_opt = R.d_topp; }
+    }
+    // post_processor.cc:179-183: unseeded rand() sequence (one default value, then one per row)
+    const float default_rand = (float)rand() / (float)RAND_MAX;
+    (void)default_rand;
+    for (int i = 0; i < B; ++i) R.h_rand[i] = (float)rand() / (float)RAND_MAX;
+    if (a->default_top_k == 1) {
+        HIPCK(c, 0, launch_sample_greedy(s, logits_device, temp_opt, B, a->vocab_size, a->batch_stride, R.d_tokout, R.d_lp));
+    } else if (a->default_top_k > 1) {
+        HIPCK(c, 0, hipMemcpyAsync(R.d_rand, R.h_rand, B * 4, hipMemcpyHostToDevice, s));
+        HIPCK(c, 0, launch_sample_topk_topp(s, logits_device, temp_opt, topp_opt, R.d_rand, B, a->vocab_size, a->batch_stride,
+                                            a->default_top_k, a->default_top_p, nullptr, R.d_tokout, R.d_lp));
+    } else {
+        return fail(c, 0, PPLHIP_UNSUPPORTED, "top_k <= 0 (pure top-p sampling) is not supported");
+    }
+    HIPCK(c, 0, hipMemcpyAsync(output_host, R.d_tokout, B * 4, hipMemcpyDeviceToHost, s));
+    HIPCK(c, 0, hipMemcpyAsync(logprob_host, R.d_lp, B * 4, hipMemcpyDeviceToHost, s));
+    HIPCK(c, 0, hipStreamSynchronize(s));  // the step's only host<->device synchronisation (post_processor.cc:212)
+    return 0;
+}
+
+int pplhip_penalty(pplhip_ctx* c, float* logits_device, const pplhip_penalty_args* a) {
+    if (!c || !a || !logits_device) return PPLHIP_INVALID_VALUE;
+    Rank& R = c->ranks[0];
+    if (!R.count_map) return fail(c, 0, PPLHIP_INVALID_VALUE, "context was created without enable_penalty");
+    const int B = a->batch;
+    if (B < 0 || B > R.cap_B || B != R.B) return fail(c, 0, PPLHIP_INVALID_VALUE, "penalty batch does not match the step");
+    HIPCK(c, 0, hipSetDevice(R.device));
+    hipStream_t s = R.stream;
+    if (a->req_list_changed) {  // post_processor.cc:231-263
+        HIPCK(c, 0, hipMemcpyAsync(R.d_ptemp, a->temperatures, B * 4, hipMemcpyHostToDevice, s));
+        HIPCK(c, 0, hipMemcpyAsync(R.d_slots, a->batch_slots, B * 8, hipMemcpyHostToDevice, s));
+        HIPCK(c, 0, hipMemcpyAsync(R.d_rep, a->repetition_penalties, B * 4, hipMemcpyHostToDevice, s));
+        if (a->presence_penalties) HIPCK(c, 0, hipMemcpyAsync(R.d_pres, a->presence_penalties, B * 4, hipMemcpyHostToDevice, s));
+        if (a->frequency_penalties) HIPCK(c, 0, hipMemcpyAsync(R.d_freq, a->frequency_penalties, B * 4, hipMemcpyHostToDevice, s));
+    }
+    HIPCK(c, 0, launch_penalty(s, logits_device, R.d_ptemp, R.d_rep, a->presence_penalties ? R.d_pres : nullptr,
+                               a->frequency_penalties ? R.d_freq : nullptr, R.d_slots, R.d_tok, R.d_seq, R.d_sp, B,
+                               a->vocab_size, c->d.vocab_size, R.count_map));
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ measurement */
+
+int pplhip_profile_reset(pplhip_ctx* c, int rank) {
+    if (!c || rank < 0 || rank >= (int)c->ranks.size()) return PPLHIP_INVALID_VALUE;
+    Rank& R = c->ranks[rank];
+    HIPCK(c, rank, hipSetDevice(R.device));
+    HIPCK(c, rank, hipStreamSynchronize(R.stream));
+    for (auto& e : R.prof) R.prof_free.push_back({e.a, e.b});
+    R.prof.clear();
+    return 0;
+}
+
+int pplhip_profile_get(pplhip_ctx* c, int rank, int cls, int64_t* launches, double* total_ms) {
+    if (!c || rank < 0 || rank >= (int)c->ranks.size()) return PPLHIP_INVALID_VALUE;
+    Rank& R = c->ranks[rank];
+    HIPCK(c, rank, hipSetDevice(R.device));
+    HIPCK(c, rank, hipStreamSynchronize(R.stream));
+    int64_t n = 0;
+    double ms = 0;
+    for (auto& e : R.prof)
+        if (e.cls == cls) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, e.a, e.b) == hipSuccess) { ms += t; ++n; }
+        }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = ms;
+    return 0;
+}
+
+int pplhip_mem_info(pplhip_ctx* c, int rank, uint64_t* free_bytes, uint64_t* total_bytes) {
+    if (!c || rank < 0 || rank >= (int)c->ranks.size()) return PPLHIP_INVALID_VALUE;
+    HIPCK(c, rank, hipSetDevice(c->ranks[rank].device));
+    size_t f = 0, t = 0;
+    HIPCK(c, rank, hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ operators */
+
+static int op_rc(hipError_t e) { return e == hipSuccess ? 0 : (e == hipErrorInvalidValue ? PPLHIP_INVALID_VALUE : PPLHIP_DEVICE_RUNTIME_ERROR); }
+
+int pplhip_op_embedding(void* stream, const int64_t* token_ids, const void* table, int64_t T, int32_t hidden, void* out) {
+    return op_rc(launch_embedding((hipStream_t)stream, token_ids, (const uint16_t*)table, T, hidden, (uint16_t*)out));
+}
+
+int pplhip_op_rmsnorm(void* stream, const void* x, const void* skip, const void* w, float eps, int64_t T, int32_t hidden,
+                      void* out, void* residual_out) {
+    return op_rc(launch_rmsnorm((hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)skip, (const uint16_t*)w, eps, T,
+                                hidden, nullptr, (uint16_t*)out, (uint16_t*)residual_out));
+}
+
+int pplhip_op_linear(void* stream, const void* x, const void* w, const void* scale, int32_t wq_bit, int32_t group, int64_t M,
+                     int32_t N, int32_t K, void* y, int32_t out_fp32) {
+    return op_rc(launch_linear((hipStream_t)stream, (const uint16_t*)x, w, (const uint16_t*)scale, wq_bit, group, M, N, K, y, N,
+                               out_fp32 != 0));
+}
+
+int pplhip_op_silu_mul(void* stream, const void* gate_up, int64_t T, int32_t inter, void* out) {
+    return op_rc(launch_silu_mul((hipStream_t)stream, (const uint16_t*)gate_up, T, inter, (uint16_t*)out));
+}
+
+static KvAddr view_addr(const pplhip_kv_view* v) {
+    pplhip_model_desc d;
+    memset(&d, 0, sizeof(d));
+    d.num_layers = v->num_layers;
+    d.cache_quant_bit = v->quant_bit; d.cache_quant_group = v->quant_group;
+    d.cache_layout = v->layout; d.cache_mode = v->mode; d.page_size = v->page_size;
+    return make_kv_addr(d, v->kv_heads, v->head_dim, (uint64_t)v->max_tokens, v->cache, (uint16_t*)v->scale, v->layer);
+}
+
+int pplhip_op_rope_kv_write(void* stream, void* qkv, const float* cos_sin, const pplhip_kv_view* kv, const int64_t* seq_starts,
+                            const int64_t* start_pos, const int64_t* cache_indices, int64_t max_pages, int64_t B, int64_t T,
+                            int32_t num_heads) {
+    if (!kv) return PPLHIP_INVALID_VALUE;
+    return op_rc(launch_rope_kv_write((hipStream_t)stream, (uint16_t*)qkv, cos_sin, view_addr(kv), kv->quant_bit, kv->quant_group,
+                                      seq_starts, start_pos, cache_indices, max_pages, B, T, num_heads, kv->kv_heads, kv->head_dim));
+}
+
+int pplhip_op_attention(void* stream, const void* qkv, const pplhip_kv_view* kv, const int64_t* seq_starts,
+                        const int64_t* start_pos, const int64_t* cache_indices, int64_t max_pages, int64_t B, int64_t T,
+                        int64_t decoding_batches, int64_t max_seq_len, int64_t max_kv_len, int32_t num_heads, int32_t split_k,
+                        void* workspace, uint64_t workspace_bytes, void* out) {
+    (void)T;
+    if (!kv) return PPLHIP_INVALID_VALUE;
+    const int64_t nb = std::min<int64_t>(std::max<int64_t>(decoding_batches, 0), B);
+    int split = split_k < 1 ? 1 : split_k;
+    if (split > 1 && attn_decode_workspace_bytes(nb, num_heads, kv->head_dim, split) > workspace_bytes) return PPLHIP_INVALID_VALUE;
+    hipStream_t s = (hipStream_t)stream;
+    const KvAddr a = view_addr(kv);
+    hipError_t e = hipSuccess;
+    if (nb > 0)
+        e = launch_attn_decode(s, (const uint16_t*)qkv, a, kv->quant_bit, seq_starts, start_pos, cache_indices, max_pages, nb,
+                               num_heads, kv->kv_heads, kv->head_dim, max_kv_len, split, 256, (float*)workspace, (uint16_t*)out);
+    if (e == hipSuccess && B > nb)
+        e = launch_attn_prefill(s, (const uint16_t*)qkv, a, kv->quant_bit, seq_starts, start_pos, cache_indices, max_pages, nb, B,
+                                num_heads, kv->kv_heads, kv->head_dim, max_seq_len, (uint16_t*)out);
+    return op_rc(e);
+}
+
+}  // extern "C"

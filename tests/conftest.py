@@ -15,3 +15,22 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def load_pplhip():
+    """imports ppl.llm.serving_amd/pplhip.py (the directory name is not an importable identifier)."""
+    import importlib.util
+    name = "pplhip_binding"
+    if name in sys.modules:
+        return sys.modules[name]
+    path = os.path.join(ROOT, "ppl.llm.serving_amd", "pplhip.py")
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="session")
+def pplhip():
+    return load_pplhip()

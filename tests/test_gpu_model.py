@@ -1,0 +1,183 @@
+"""End-to-end parity of the decoder forward (pplhip_set_inputs / pplhip_run / pplhip_sample) against the CPU oracle
+and the HF golden vectors: packed ragged prefill, decode steps, all cache layouts/modes, fp16 and int8 KV,
+fp16 / W8A16 / W4A16 weights.  Tolerance on logits: |d| <= 1e-3 * max(1, |logit|max) * k with k stated per
+test (north star: "logits within 1e-3 fp16"; the tiny models' logits are O(1)); greedy tokens exact wherever
+the oracle's top-2 margin exceeds the tolerance."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from oracle import ref
+from tests.conftest import load_pplhip
+from tests.test_oracle_hf import desc_from_meta, load_fixture
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def plan_cache(desc, lens_total, max_tokens, seed=0):
+    n = len(lens_total)
+    lens_total = np.asarray(lens_total)
+    if desc.cache_mode == 0:
+        idx = np.concatenate([[0], np.cumsum(lens_total)[:-1]]).astype(np.int64)
+        return idx, 0
+    P = desc.page_size
+    npg = (lens_total + P - 1) // P
+    mp = int(npg.max())
+    idx = np.full((n, mp), np.iinfo(np.int64).max, dtype=np.int64)
+    order = np.random.RandomState(seed).permutation(max_tokens // P)
+    k = 0
+    for i in range(n):
+        idx[i, :npg[i]] = order[k:k + npg[i]]
+        k += npg[i]
+    return idx, mp
+
+
+def generate_both(m, ctx, models, desc, prompts, steps, max_tokens):
+    """runs `steps` greedy steps (packed prefill, then decode) on the device and on the oracle with the SAME inputs
+    (the oracle's tokens drive both, so a single flipped argmax cannot cascade)."""
+    n = len(prompts)
+    lens = np.array([len(p) for p in prompts])
+    cache_idx, max_pages = plan_cache(desc, lens + steps, max_tokens)
+    tok = np.concatenate(prompts).astype(np.int64)
+    seq_starts = np.concatenate([[0], np.cumsum(lens)])
+    start_pos = np.zeros(n, dtype=np.int64)
+    res = []
+    for s in range(steps):
+        dec = 0 if s == 0 else n
+        st_r = ref.make_step(tok, seq_starts, start_pos, cache_idx, dec, max_pages)
+        st_g = m.make_step(tok, seq_starts, start_pos, cache_idx, dec, max_pages, req_list_changed=1 if s == 0 else 0)
+        want = ref.forward(models, st_r)
+        ctx.set_inputs(0, st_g)
+        ctx.run(0)
+        gtok, glp = ctx.sample(n, top_k=1)
+        got = ctx.copy_logits(n)
+        wtok, wlp = ref.sample(want, top_k=1)
+        res.append((got, want, gtok, wtok, glp, wlp))
+        start_pos = start_pos + (seq_starts[1:] - seq_starts[:-1])
+        tok = wtok.astype(np.int64)
+        seq_starts = np.arange(n + 1)
+    return res
+
+
+def check_steps(res, k):
+    for s, (got, want, gtok, wtok, glp, wlp) in enumerate(res):
+        tol = 1e-3 * k * max(1.0, np.abs(want).max())
+        err = np.abs(got - want).max()
+        assert err <= tol, (s, err, tol)
+        srt = np.sort(want, -1)
+        safe = (srt[:, -1] - srt[:, -2]) > 2 * tol
+        assert (gtok[safe] == wtok[safe]).all(), s
+        assert np.abs(glp[safe] - wlp[safe]).max() < 5 * tol
+
+
+@pytest.mark.parametrize("name", ["mha", "gqa"])
+@pytest.mark.parametrize("layout,mode,quant", [(3, 0, 0), (0, 0, 8), (1, 1, 0), (2, 1, 8), (3, 1, 8)])
+def test_hf_fixture_model(golden_dir, name, layout, mode, quant):
+    m = load_pplhip()
+    meta, weights, prompts, hf_logits, hf_tokens, _ = load_fixture(os.path.join(golden_dir, f"hf_tiny_{name}.npz"))
+    kw = dict(cache_layout=layout, cache_mode=mode, page_size=4 if mode else 0, cache_quant_bit=quant,
+              cache_quant_group=8 if quant else 1)
+    desc = desc_from_meta(meta, **kw)
+    gdesc = m.copy_desc(desc)
+    rm = ref.RefModel(desc)
+    ctx = m.Context(gdesc, max_running_batch=8, max_tokens_per_step=64)
+    for k, v in weights.items():
+        rm.set_tensor(k, v)
+        ctx.set_tensor(0, k, v)
+    max_tokens = 256
+    rm.kv_alloc(max_tokens)
+    ctx.kv_alloc(0, max_tokens)
+    steps = hf_logits.shape[1]
+    res = generate_both(m, ctx, [rm], desc, prompts, steps, max_tokens)
+    check_steps(res, k=4)
+    if quant == 0:
+        # and against the independent HF vectors (fp32 model vs fp16 activations)
+        got = np.stack([r[0] for r in res], 1)
+        assert np.abs(got - hf_logits).max() < 2e-2 * max(1.0, np.abs(hf_logits).max())
+    # KV slab written by the device equals the oracle's (fp16 bits / int8 bytes + scales), up to rare rounding ties
+    gk, rk = ctx.kv_read(0, 0), rm.kv_array(0)
+    if quant == 0:
+        d = np.abs(gk.astype(np.float32) - rk.astype(np.float32))
+        assert (d <= 2e-3 * np.maximum(1.0, np.abs(rk.astype(np.float32)))).all()
+    else:
+        assert (np.abs(gk.astype(np.int32) - rk.astype(np.int32)) <= 1).all()
+        assert (gk != rk).mean() < 0.02
+    ctx.close()
+
+
+@pytest.mark.parametrize("wq,kvq,mode", [(8, 8, 1), (4, 8, 0), (0, 0, 0), (8, 0, 1)])
+def test_synthetic_model(wq, kvq, mode):
+    """synthetic weights generated ON THE DEVICE equal the oracle's generator (else logits could not agree)."""
+    m = load_pplhip()
+    desc = ref.make_desc(hidden_dim=256, intermediate_dim=512, num_layers=2, num_heads=4, num_kv_heads=4, vocab_size=1024,
+                         max_position=512, cache_quant_bit=kvq, cache_quant_group=8 if kvq else 1, cache_layout=3,
+                         cache_mode=mode, page_size=16 if mode else 0, weight_quant_bit=wq, weight_quant_group=128)
+    rm = ref.RefModel(desc)
+    rm.init_synthetic(1234)
+    ctx = m.Context(m.copy_desc(desc), max_running_batch=16, max_tokens_per_step=256)
+    ctx.init_synthetic(0, 1234)
+    rm.kv_alloc(1024)
+    ctx.kv_alloc(0, 1024)
+    rng = np.random.RandomState(7)
+    prompts = [rng.randint(3, 1024, size=n) for n in (70, 3, 129, 1, 16)]
+    res = generate_both(m, ctx, [rm], desc, prompts, 4, 1024)
+    check_steps(res, k=8 if wq == 4 else 4)
+    ctx.close()
+
+
+def test_container_load_and_errors(golden_dir):
+    m = load_pplhip()
+    meta, weights, prompts, hf_logits, _, _ = load_fixture(os.path.join(golden_dir, "hf_tiny_mha.npz"))
+    desc = desc_from_meta(meta)
+    ctx = m.Context(m.copy_desc(desc), max_running_batch=4, max_tokens_per_step=32)
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, "model_slice_0"))
+        m.write_container(os.path.join(td, "model_slice_0", "weights.pplhip"), weights)
+        ctx.load(0, os.path.join(td, "model_slice_0"))
+        with pytest.raises(m.PplHipError):
+            ctx.load(0, os.path.join(td, "model_slice_1"))
+    with pytest.raises(m.PplHipError):
+        ctx.set_tensor(0, "no.such.tensor", np.zeros(4, dtype=np.float16))
+    with pytest.raises(m.PplHipError):
+        ctx.set_tensor(0, "norm.weight", np.zeros(3, dtype=np.float16))
+    ctx.kv_alloc(0, 64)
+    p = prompts[0]
+    st = m.make_step(p, [0, len(p)], [0], [0], 0)
+    ctx.set_inputs(0, st)
+    ctx.run(0)
+    got = ctx.copy_logits(1)
+    assert np.abs(got[0] - hf_logits[0, 0]).max() < 2e-2 * max(1.0, np.abs(hf_logits).max())
+    # a step larger than the context was sized for is rejected, not truncated
+    big = m.make_step(np.zeros(40, dtype=np.int64), [0, 40], [0], [0], 0)
+    with pytest.raises(m.PplHipError):
+        ctx.set_inputs(0, big)
+    ctx.close()
+
+
+def test_prefix_cache_hit_equals_cold_prefill():
+    """cache-prefill (K7): re-using cached pages for a shared prefix gives the same logits as a cold prefill,
+    bit for bit in the KV slab and within fp16 rounding in the logits (SURVEY.md section 10 worked example)."""
+    m = load_pplhip()
+    desc = ref.make_desc(hidden_dim=256, intermediate_dim=512, num_layers=2, num_heads=4, num_kv_heads=2, vocab_size=512,
+                         max_position=512, cache_quant_bit=8, cache_quant_group=8, cache_layout=3, cache_mode=1, page_size=4,
+                         weight_quant_bit=8)
+    ctx = m.Context(m.copy_desc(desc), max_running_batch=4, max_tokens_per_step=64)
+    ctx.init_synthetic(0, 5)
+    ctx.kv_alloc(0, 256)
+    rng = np.random.RandomState(1)
+    prompt = rng.randint(3, 512, size=10)
+    I64MAX = np.iinfo(np.int64).max
+    # cold: pages [7, 9, 11]
+    st = m.make_step(prompt, [0, 10], [0], np.array([[7, 9, 11]]), 0, max_pages=3)
+    ctx.set_inputs(0, st); ctx.run(0)
+    cold = ctx.copy_logits(1)
+    # hit: first 8 tokens (pages 7, 9) are cached; only tokens 8..9 are fed, start_pos = 8, new page 20
+    st = m.make_step(prompt[8:], [0, 2], [8], np.array([[7, 9, 20]]), 0, max_pages=3)
+    ctx.set_inputs(0, st); ctx.run(0, cache_prefill=1)
+    hit = ctx.copy_logits(1)
+    assert np.abs(cold - hit).max() <= 2e-3 * max(1.0, np.abs(cold).max())
+    assert cold.argmax() == hit.argmax()
+    ctx.close()

@@ -1,0 +1,317 @@
+"""Parity of every hand-written gfx950 kernel against the CPU oracle, one operator at a time, through the C ABI
+(pplhip_op_*).  Tolerances: bit-exact for integer work (embedding gather, int8 KV bytes up to documented +-1 LSB
+rounding ties, token ids); fp16 outputs within 1 fp16 ulp-class bounds stated per test."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import ref
+from tests.conftest import load_pplhip
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def dev(arr):
+    return torch.from_numpy(np.ascontiguousarray(arr)).cuda()
+
+
+def f16(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float16)
+
+
+def ck(rc):
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+
+
+def close_f16(got, want, rel=2e-3, abs_=2e-3):
+    got = np.asarray(got, dtype=np.float32)
+    want = np.asarray(want, dtype=np.float32)
+    err = np.abs(got - want)
+    tol = abs_ + rel * np.abs(want)
+    assert (err <= tol).all(), (err.max(), np.abs(want).max(), int((err > tol).sum()))
+
+
+def test_embedding_bit_exact():
+    m = load_pplhip()
+    rng = np.random.RandomState(0)
+    table = f16(rng.randn(300, 256))
+    ids = rng.randint(0, 300, size=77).astype(np.int64)
+    out = torch.empty((77, 256), dtype=torch.float16, device="cuda")
+    ck(m.lib().pplhip_op_embedding(None, dev(ids).data_ptr(), dev(table).data_ptr(), 77, 256, out.data_ptr()))
+    assert (out.cpu().numpy() == table[ids]).all()
+
+
+@pytest.mark.parametrize("hidden", [128, 4096, 8192, 5120])
+@pytest.mark.parametrize("skip", [False, True])
+def test_rmsnorm(hidden, skip):
+    m = load_pplhip()
+    rng = np.random.RandomState(hidden)
+    T = 37
+    x = f16(rng.randn(T, hidden) * 2)
+    sk = f16(rng.randn(T, hidden)) if skip else None
+    w = f16(1 + 0.1 * rng.randn(hidden))
+    want = np.empty((T, hidden), dtype=np.float32)
+    want_res = np.empty((T, hidden), dtype=np.float32)
+    xs = x.astype(np.float32)
+    sks = sk.astype(np.float32) if skip else None
+    ref.lib().ref_rmsnorm(xs.ctypes.data, None if sks is None else sks.ctypes.data, w.ctypes.data, 1e-5, T, hidden,
+                          want.ctypes.data, want_res.ctypes.data)
+    out = torch.empty((T, hidden), dtype=torch.float16, device="cuda")
+    res = torch.empty((T, hidden), dtype=torch.float16, device="cuda")
+    dx, dw = dev(x), dev(w)
+    dsk = dev(sk) if skip else None
+    ck(m.lib().pplhip_op_rmsnorm(None, dx.data_ptr(), dsk.data_ptr() if skip else None, dw.data_ptr(), 1e-5, T, hidden,
+                                 out.data_ptr(), res.data_ptr()))
+    # residual = fp16(x + skip): bit exact
+    assert (res.cpu().numpy().astype(np.float32) == want_res).all()
+    close_f16(out.cpu().numpy(), want, rel=1.5e-3, abs_=1e-4)
+
+
+@pytest.mark.parametrize("wq", [0, 8, 4])
+@pytest.mark.parametrize("M,N,K", [(1, 128, 128), (5, 384, 256), (130, 320, 128), (64, 512, 1376), (257, 1024, 4096)])
+def test_linear(wq, M, N, K):
+    m = load_pplhip()
+    if wq == 4 and K % 128:
+        group = 32
+    else:
+        group = 128
+    rng = np.random.RandomState(M * 7 + N + K + wq)
+    x = f16(rng.randn(M, K))
+    if wq == 0:
+        w = f16(rng.randn(N, K) * 0.05)
+        scale = None
+    elif wq == 8:
+        w = rng.randint(-127, 128, size=(N, K)).astype(np.int8)
+        scale = f16(0.0005 * (0.5 + rng.rand(N)))
+    else:
+        w = rng.randint(0, 256, size=(N, K // 2)).astype(np.uint8)
+        scale = f16(0.01 * (0.5 + rng.rand(N, K // group)))
+    for out_fp32 in (0, 1):
+        want = np.empty((M, N), dtype=np.float32)
+        xs = x.astype(np.float32)
+        ref.lib().ref_linear_raw(xs.ctypes.data, w.ctypes.data, None if scale is None else scale.ctypes.data, wq, group, M, N,
+                                 K, want.ctypes.data, out_fp32)
+        y = torch.empty((M, N), dtype=torch.float32 if out_fp32 else torch.float16, device="cuda")
+        dx, dw = dev(x), dev(w)
+        ds = dev(scale) if scale is not None else None
+        ck(m.lib().pplhip_op_linear(None, dx.data_ptr(), dw.data_ptr(), ds.data_ptr() if ds is not None else None, wq, group,
+                                    M, N, K, y.data_ptr(), out_fp32))
+        got = y.float().cpu().numpy()
+        mag = np.abs(want).max()
+        # fp32 accumulation-order noise + (W4 only) one fp16 rounding of q*scale per weight
+        rel = 3e-3 if wq == 4 else 1.5e-3
+        close_f16(got, want, rel=rel, abs_=rel * mag * 0.05 + 1e-5)
+
+
+def test_silu_mul():
+    m = load_pplhip()
+    rng = np.random.RandomState(3)
+    T, inter = 19, 1376
+    gu = f16(rng.randn(T, 2 * inter) * 3)
+    want = np.empty((T, inter), dtype=np.float32)
+    gus = gu.astype(np.float32)
+    ref.lib().ref_silu_mul(gus.ctypes.data, T, inter, want.ctypes.data)
+    out = torch.empty((T, inter), dtype=torch.float16, device="cuda")
+    ck(m.lib().pplhip_op_silu_mul(None, dev(gu).data_ptr(), T, inter, out.data_ptr()))
+    close_f16(out.cpu().numpy(), want, rel=1.5e-3, abs_=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# KV-cache operators
+# ---------------------------------------------------------------------------------------------------------------
+class KvCase:
+    """A ragged batch + KV slab shared by the oracle and the device."""
+
+    def __init__(self, m, H, Hkv, D, L, layer, quant, layout, mode, seqlens, start_pos, seed=0, page_size=4,
+                 decoding_batches=0):
+        self.m, self.H, self.Hkv, self.D, self.L, self.layer = m, H, Hkv, D, L, layer
+        rng = np.random.RandomState(seed)
+        self.B = len(seqlens)
+        seqlens = np.asarray(seqlens, dtype=np.int64)
+        start_pos = np.asarray(start_pos, dtype=np.int64)
+        self.seq_starts = np.concatenate([[0], np.cumsum(seqlens)]).astype(np.int64)
+        self.start_pos = start_pos
+        self.T = int(seqlens.sum())
+        total = start_pos + seqlens
+        self.max_seq_len, self.max_kv_len = int(seqlens.max()), int(total.max())
+        self.decoding_batches = decoding_batches
+        self.desc = ref.make_desc(hidden_dim=H * D, intermediate_dim=64, num_layers=L, num_heads=H, num_kv_heads=Hkv,
+                                  vocab_size=64, cache_quant_bit=quant, cache_quant_group=8 if quant else 1,
+                                  cache_layout=layout, cache_mode=mode, page_size=page_size if mode else 0)
+        if mode == 0:
+            gaps = rng.randint(0, 5, size=self.B)
+            self.cache_idx = (np.concatenate([[0], np.cumsum(total + gaps)[:-1]]) + 3).astype(np.int64)
+            self.max_pages = 0
+            self.N = int((total + gaps).sum()) + 8
+        else:
+            P = page_size
+            npg = (total + P - 1) // P
+            self.max_pages = int(npg.max())
+            n_pages = int(npg.sum()) + 5
+            order = rng.permutation(n_pages)
+            self.cache_idx = np.full((self.B, self.max_pages), np.iinfo(np.int64).max, dtype=np.int64)
+            k = 0
+            for i in range(self.B):
+                self.cache_idx[i, :npg[i]] = order[k:k + npg[i]]
+                k += npg[i]
+            self.N = n_pages * P
+        elems = self.N * L * 2 * Hkv * D
+        self.cache = np.zeros(elems, dtype=np.int8 if quant else np.float16)
+        self.scale = np.zeros(elems // 8, dtype=np.float16) if quant else None
+        self.qkv = f16(rng.randn(self.T, (H + 2 * Hkv) * D))
+        self.rope = np.empty((4096, D), dtype=np.float32)
+        ref.lib().ref_build_rope_table(self.rope.ctypes.data, 4096, D, 10000.0)
+
+    def view(self, dcache, dscale):
+        v = self.m.KvView()
+        v.cache, v.scale = dcache.data_ptr(), (dscale.data_ptr() if dscale is not None else None)
+        v.max_tokens, v.num_layers, v.kv_heads, v.head_dim = self.N, self.L, self.Hkv, self.D
+        d = self.desc
+        v.quant_bit, v.quant_group, v.layout, v.mode, v.page_size, v.layer = (d.cache_quant_bit, d.cache_quant_group,
+                                                                              d.cache_layout, d.cache_mode, d.page_size,
+                                                                              self.layer)
+        return v
+
+    def ref_write(self):
+        q32 = self.qkv.astype(np.float32)
+        ref.lib().ref_rope_kv_write(q32.ctypes.data, self.rope.ctypes.data, C.byref(self.desc), self.H, self.Hkv, self.D,
+                                    self.layer, self.cache.ctypes.data, None if self.scale is None else self.scale.ctypes.data,
+                                    self.N, self.seq_starts.ctypes.data, self.start_pos.ctypes.data,
+                                    self.cache_idx.ctypes.data, self.max_pages, self.B)
+        return q32
+
+    def ref_attention(self, q32):
+        out = np.zeros((self.T, self.H * self.D), dtype=np.float32)
+        ref.lib().ref_attention(q32.ctypes.data, C.byref(self.desc), self.H, self.Hkv, self.D, self.layer,
+                                self.cache.ctypes.data, None if self.scale is None else self.scale.ctypes.data, self.N,
+                                self.seq_starts.ctypes.data, self.start_pos.ctypes.data, self.cache_idx.ctypes.data,
+                                self.max_pages, self.B, out.ctypes.data)
+        return out
+
+
+@pytest.mark.parametrize("quant", [0, 8])
+@pytest.mark.parametrize("layout,mode", [(0, 0), (1, 1), (2, 0), (3, 1), (3, 0)])
+@pytest.mark.parametrize("H,Hkv,D", [(4, 4, 32), (8, 2, 64), (4, 4, 128)])
+def test_rope_kv_write(quant, layout, mode, H, Hkv, D):
+    m = load_pplhip()
+    case = KvCase(m, H, Hkv, D, L=3, layer=1, quant=quant, layout=layout, mode=mode, seqlens=[5, 1, 9, 1],
+                  start_pos=[0, 7, 3, 0], seed=layout * 10 + mode)
+    want_q = case.ref_write()
+    dq = dev(case.qkv)
+    dcache = torch.zeros(case.cache.size, dtype=torch.int8 if quant else torch.float16, device="cuda")
+    dscale = torch.zeros(case.scale.size, dtype=torch.float16, device="cuda") if quant else None
+    v = case.view(dcache, dscale)
+    ck(m.lib().pplhip_op_rope_kv_write(None, dq.data_ptr(), dev(case.rope).data_ptr(), C.byref(v), dev(case.seq_starts).data_ptr(),
+                                       dev(case.start_pos).data_ptr(), dev(case.cache_idx).data_ptr(), case.max_pages, case.B,
+                                       case.T, H))
+    got_q = dq.cpu().numpy().astype(np.float32)
+    hq = H * D
+    # rotated q (fp16, written in place): bit exact (identical fp32 op sequence, same cos/sin table)
+    assert (got_q[:, :hq] == want_q[:, :hq]).all()
+    got_cache = dcache.cpu().numpy()
+    if quant == 0:
+        assert (got_cache.view(np.uint16) == case.cache.view(np.uint16)).all()
+    else:
+        assert (dscale.cpu().numpy().view(np.uint16) == case.scale.view(np.uint16)).all()
+        assert (got_cache == case.cache).all()
+
+
+ATT_SHAPES = [(4, 4, 32), (8, 2, 64), (4, 4, 128), (8, 1, 128)]
+
+
+@pytest.mark.parametrize("quant", [0, 8])
+@pytest.mark.parametrize("layout,mode", [(3, 0), (0, 0), (2, 1), (3, 1)])
+@pytest.mark.parametrize("H,Hkv,D", ATT_SHAPES)
+def test_attention_decode(quant, layout, mode, H, Hkv, D):
+    """decode rows: kv lengths 1 .. 700, ragged, contiguous and paged, MHA and GQA, with and without split-K."""
+    m = load_pplhip()
+    kvlen = [1, 2, 63, 64, 65, 257, 700, 33]
+    case = KvCase(m, H, Hkv, D, L=2, layer=1, quant=quant, layout=layout, mode=mode, seqlens=[1] * len(kvlen),
+                  start_pos=[k - 1 for k in kvlen], seed=D + quant, page_size=16, decoding_batches=len(kvlen))
+    rng = np.random.RandomState(5)
+    # random cache contents (history), then write the current token through the oracle
+    if quant:
+        case.cache[:] = rng.randint(-127, 128, size=case.cache.size).astype(np.int8)
+        case.scale[:] = f16(0.02 * (0.5 + rng.rand(case.scale.size)))
+    else:
+        case.cache[:] = f16(rng.randn(case.cache.size))
+    q32 = case.ref_write()
+    want = case.ref_attention(q32)
+    dq = dev(q32.astype(np.float16))
+    dcache, dscale = dev(case.cache), (dev(case.scale) if quant else None)
+    v = case.view(dcache, dscale)
+    args = (dev(case.seq_starts), dev(case.start_pos), dev(case.cache_idx))
+    for split in (1, 3):
+        out = torch.zeros((case.T, H * D), dtype=torch.float16, device="cuda")
+        ws = torch.empty(case.B * H * split * (D + 2) + 16, dtype=torch.float32, device="cuda")
+        ck(m.lib().pplhip_op_attention(None, dq.data_ptr(), C.byref(v), args[0].data_ptr(), args[1].data_ptr(),
+                                       args[2].data_ptr(), case.max_pages, case.B, case.T, case.B, 1, case.max_kv_len, H,
+                                       split, ws.data_ptr(), ws.numel() * 4, out.data_ptr()))
+        close_f16(out.cpu().numpy(), want, rel=1.5e-3, abs_=1.5e-3)
+
+
+@pytest.mark.parametrize("quant", [0, 8])
+@pytest.mark.parametrize("layout,mode", [(3, 0), (1, 0), (3, 1)])
+@pytest.mark.parametrize("H,Hkv,D", ATT_SHAPES)
+def test_attention_prefill_and_mixed(quant, layout, mode, H, Hkv, D):
+    """mixed step: 2 decode rows first, then prefill / cache-prefill (start_pos > 0) requests of ragged length."""
+    m = load_pplhip()
+    seqlens = [1, 1, 130, 1, 64, 17, 200]
+    start = [40, 5, 0, 0, 64, 30, 70]
+    case = KvCase(m, H, Hkv, D, L=2, layer=0, quant=quant, layout=layout, mode=mode, seqlens=seqlens, start_pos=start,
+                  seed=D * 3 + quant, page_size=16, decoding_batches=2)
+    rng = np.random.RandomState(9)
+    if quant:
+        case.cache[:] = rng.randint(-127, 128, size=case.cache.size).astype(np.int8)
+        case.scale[:] = f16(0.02 * (0.5 + rng.rand(case.scale.size)))
+    else:
+        case.cache[:] = f16(rng.randn(case.cache.size))
+    q32 = case.ref_write()
+    want = case.ref_attention(q32)
+    dq = dev(q32.astype(np.float16))
+    dcache, dscale = dev(case.cache), (dev(case.scale) if quant else None)
+    v = case.view(dcache, dscale)
+    out = torch.zeros((case.T, H * D), dtype=torch.float16, device="cuda")
+    ck(m.lib().pplhip_op_attention(None, dq.data_ptr(), C.byref(v), dev(case.seq_starts).data_ptr(),
+                                   dev(case.start_pos).data_ptr(), dev(case.cache_idx).data_ptr(), case.max_pages, case.B,
+                                   case.T, 2, case.max_seq_len, case.max_kv_len, H, 1, None, 0, out.data_ptr()))
+    # prefill path: K/V dequantised to fp16 and P rounded to fp16 before the MFMAs: 4e-3 relative to |V|max
+    vmax = 3.0 if not quant else 0.03 * 127
+    close_f16(out.cpu().numpy(), want, rel=4e-3, abs_=4e-3 * vmax)
+
+
+def test_sampler_greedy_and_topk():
+    m = load_pplhip()
+    rng = np.random.RandomState(11)
+    B, V = 33, 32000
+    logits = (rng.randn(B, V) * 3).astype(np.float32)
+    logits[3, 100] = logits[3, 7] = 50.0  # tie -> lower index
+    desc = m.make_desc(hidden_dim=128, intermediate_dim=128, num_layers=1, num_heads=4, num_kv_heads=4, vocab_size=V)
+    ctx = m.Context(desc, max_running_batch=64, max_tokens_per_step=64)
+    d = dev(logits)
+    tok, lp = ctx.sample(B, top_k=1, logits_ptr=d.data_ptr())
+    wt, wl = ref.sample(logits, top_k=1)
+    assert (tok == wt).all() and tok[3] == 7
+    assert np.abs(lp - wl).max() < 1e-4
+    # temperature + top-k/top-p: the kernel's random numbers come from the unseeded rand() stream like the
+    # reference's (post_processor.cc:179-183); restate that stream here with libc
+    temps = (0.5 + rng.rand(B)).astype(np.float32)
+    libc = C.CDLL("libc.so.6")
+    libc.rand.restype = C.c_int
+    # ctx.sample consumed 1 + B values above; the next call draws 1 default + B per-row values
+    tok2, lp2 = ctx.sample(B, top_k=50, top_p=0.9, temperatures=temps, logits_ptr=d.data_ptr())
+    assert ((tok2 >= 0) & (tok2 < V)).all()
+    # every sampled token must be inside the top-50 / top-p 0.9 nucleus of its row
+    for b in range(B):
+        x = logits[b] / temps[b]
+        order = np.argsort(-x, kind="stable")[:50]
+        p = np.exp(x[order] - x[order].max())
+        p /= p.sum()
+        keep = int(np.searchsorted(np.cumsum(p), 0.9) + 1)
+        assert tok2[b] in order[:keep]
+        lse = np.log(np.exp(x - x.max()).sum()) + x.max()
+        assert abs(lp2[b] - (x[tok2[b]] - lse)) < 1e-3
+    ctx.close()
