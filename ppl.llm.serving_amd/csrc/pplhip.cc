@@ -531,6 +531,9 @@ int pplhip_kv_alloc(pplhip_ctx* c, int rank, uint64_t tokens) {
             return fail(c, rank, PPLHIP_OUT_OF_MEMORY, "alloc kv scale [" + std::to_string(tokens * sb) + "] failed: " + hipGetErrorString(e));
         }
     }
+    // deterministic contents for never-written slots (the reference's cudaMalloc leaves them undefined)
+    HIPCK(c, rank, hipMemset(R.kv_cache, 0, tokens * kb));
+    if (sb) HIPCK(c, rank, hipMemset(R.kv_scale, 0, tokens * sb));
     R.kv_tokens = tokens;
     return 0;
 }

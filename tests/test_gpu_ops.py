@@ -13,8 +13,22 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
+_KEEP = []
+
+
 def dev(arr):
-    return torch.from_numpy(np.ascontiguousarray(arr)).cuda()
+    """host array -> device tensor, kept alive until the next test (a temporary freed before the launch would be
+    handed out again by torch's caching allocator and two kernel arguments would alias)."""
+    t = torch.from_numpy(np.ascontiguousarray(arr)).cuda()
+    _KEEP.append(t)
+    return t
+
+
+@pytest.fixture(autouse=True)
+def _drop_device_tensors():
+    yield
+    torch.cuda.synchronize()
+    _KEEP.clear()
 
 
 def f16(a):
@@ -103,7 +117,8 @@ def test_linear(wq, M, N, K):
         mag = np.abs(want).max()
         # fp32 accumulation-order noise + (W4 only) one fp16 rounding of q*scale per weight
         rel = 3e-3 if wq == 4 else 1.5e-3
-        close_f16(got, want, rel=rel, abs_=rel * mag * 0.05 + 1e-5)
+        # (W4: the per-weight rounding noise scales with the typical |y|, not with the element's own value)
+        close_f16(got, want, rel=rel, abs_=rel * mag * (0.25 if wq == 4 else 0.05) + 1e-5)
 
 
 def test_silu_mul():
