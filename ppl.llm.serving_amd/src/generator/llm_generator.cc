@@ -133,13 +133,16 @@ void* LLMGenerator::GeneratorThreadFunc(void* arg) {
                 return nullptr;
             }
             if (g->sched_.GetPendingSize() > 0) {
+                g->generating_.store(true, std::memory_order_release);
                 g->req_signal_.CancelWait();
                 break;
             }
             LOG(INFO) << "waiting for request ...";
             g->req_signal_.CommitWait(key);
         }
+        g->generating_.store(true, std::memory_order_release);
         g->Generate();
+        g->generating_.store(false, std::memory_order_release);
     }
     return nullptr;
 }

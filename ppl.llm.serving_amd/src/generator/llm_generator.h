@@ -99,6 +99,8 @@ public:
 
     void SetStepObserver(StepObserver f, void* arg) { observer_ = f; observer_arg_ = arg; }
     const WorkerProfiler& GetProfiler() const { return *worker_profiler_; }
+    // nothing queued and no batch running (tools use it to drain before shutdown)
+    bool IsIdle() const { return sched_.GetPendingSize() == 0 && !generating_.load(std::memory_order_acquire); }
 
 private:
     struct Admission;  // scratch of one admission check (RequestCheckResult in the reference)
@@ -137,6 +139,7 @@ private:
     std::shared_ptr<WorkerProfiler> worker_profiler_;
 
     std::atomic<bool> generate_thread_active_{false};
+    std::atomic<bool> generating_{false};
     pthread_t generate_thread_;
     ppl::common::EventCount req_signal_;
     utils::MPSCRequestScheduler<LlmRequest> sched_;
