@@ -1,0 +1,86 @@
+"""The C++ host stack on the GPU: tools/offline_inference (LLMGenerator -> LLMEngine -> src/backends/hip -> libpplhip)
+against the oracle's greedy continuation of the same prompts, and the prefix-cache benchmark driver."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import ref
+from tests.conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+PKG = os.path.join(ROOT, "ppl.llm.serving_amd")
+CFG = os.path.join(PKG, "configs", "tiny_w8a16_kv8_paged.json")
+
+
+def tool(name):
+    path = os.path.join(PKG, "build", name)
+    assert os.path.exists(path), f"{path} missing: run __graft_entry__.build()"
+    return path
+
+
+def oracle_greedy(desc, seed, prompt, n):
+    """greedy continuation of one prompt; also returns the top-2 margin of every step"""
+    m = ref.RefModel(desc)
+    m.init_synthetic(seed)
+    total = len(prompt) + n
+    m.kv_alloc(((total + 3) // 4) * 4)
+    pages = np.arange((total + 3) // 4, dtype=np.int64)[None, :]
+    toks, margins = [], []
+    tok, start = np.asarray(prompt, dtype=np.int64), 0
+    for s in range(n):
+        st = ref.make_step(tok, [0, len(tok)], [start], pages, 0 if s == 0 else 1, max_pages=pages.shape[1])
+        logits = ref.forward([m], st)[0]
+        srt = np.sort(logits)
+        margins.append(float(srt[-1] - srt[-2]))
+        nxt = int(logits.argmax())
+        toks.append(nxt)
+        start += len(tok)
+        tok = np.array([nxt], dtype=np.int64)
+    return toks, margins
+
+
+def test_offline_inference_prompts4_matches_oracle():
+    out = subprocess.check_output([tool("offline_inference"), "--model-param-path", CFG, "--synthetic-weights", "--synthetic-seed", "77",
+                                   "--kv-cache-max-tokens", "512", "--max-running-batch", "8", "--max-tokens-per-step", "64",
+                                   "--workload", "prompts4"], timeout=300).decode()
+    prompts, answers = [], []
+    for line in out.splitlines():
+        if line.startswith("Prompt tokens:"):
+            prompts.append([int(x) for x in line.split(":")[1].split()])
+        if line.startswith("Answer tokens:"):
+            answers.append([int(x) for x in line.split(":")[1].split()])
+    assert len(prompts) == 4 and [len(a) for a in answers] == [8, 9, 10, 11]     # generation_length = 8 + i
+    assert "generation time:" in out
+    cfg = json.load(open(CFG))
+    desc = ref.make_desc(hidden_dim=cfg["hidden_dim"], intermediate_dim=cfg["intermediate_dim"], num_layers=cfg["num_layers"],
+                         num_heads=cfg["num_heads"], num_kv_heads=cfg["num_kv_heads"], vocab_size=cfg["vocab_size"],
+                         max_position=cfg["max_position"], cache_quant_bit=8, cache_quant_group=8, cache_layout=3, cache_mode=1,
+                         page_size=4, weight_quant_bit=8)
+    compared = 0
+    for p, a in zip(prompts, answers):
+        want, margins = oracle_greedy(desc, 77, p, len(a))
+        for i, (g, w) in enumerate(zip(a, want)):
+            if margins[i] < 2e-2:      # near-tie: either choice is legitimate, and the continuations diverge
+                break
+            assert g == w, (p, i, a, want)
+            compared += 1
+    assert compared >= 20
+
+
+def test_offline_inference_samples_workload_and_prefix_benchmark():
+    out = subprocess.check_output([tool("offline_inference"), "--model-param-path", CFG, "--synthetic-weights",
+                                   "--kv-cache-max-tokens", "2048", "--max-running-batch", "16", "--max-tokens-per-step", "256",
+                                   "--workload", "samples1024", "--num-requests", "48", "--max-seq-len", "128"], timeout=300).decode()
+    res = json.loads(out.strip().splitlines()[-1])
+    assert res["failed"] == 0 and res["requests"] == 48 and res["output_tokens"] > 48
+    assert res["max_running"] <= 16 and res["ttft_ms"]["p50"] > 0 and res["tokens_out_per_s"] > 0
+    out = subprocess.check_output([tool("benchmark_prefix_cache_offline"), "--model-param-path", CFG, "--synthetic-weights",
+                                   "--kv-cache-max-tokens", "2048", "--max-running-batch", "4", "--max-tokens-per-step", "512",
+                                   "--max-input-tokens-per-request", "512", "--enable-prefix-cache", "--prompt-len", "200",
+                                   "--shared-len", "160", "--generation-length", "8"], timeout=300).decode()
+    res = json.loads(out.strip().splitlines()[-1])
+    assert res["first_ttft_ms"] > 0 and res["prefix_ttft_ms"] > 0
+    assert "first ttft:" in out and "prefix ttft:" in out
