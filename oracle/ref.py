@@ -68,12 +68,26 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _DIR])
 
 
+def usable_cpus():
+    """CPUs this process may really use: min(affinity mask, cgroup cpu.max quota).  The GPU boxes expose 256 logical
+    CPUs but cap the container at a 16-CPU quota; 256 OpenMP threads on that quota are ~100x slower than 16."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(_DIR, "libllama_ref.so")
         if not os.path.exists(path):
             build()
+        os.environ.setdefault("OMP_NUM_THREADS", str(usable_cpus()))  # read by libgomp when the library loads
         L = C.CDLL(path)
         L.ref_create.restype = C.c_void_p
         L.ref_create.argtypes = [C.POINTER(ModelDesc), C.c_int, C.c_int]

@@ -63,11 +63,11 @@ def test_offline_inference_prompts4_matches_oracle():
     for p, a in zip(prompts, answers):
         want, margins = oracle_greedy(desc, 77, p, len(a))
         for i, (g, w) in enumerate(zip(a, want)):
-            if margins[i] < 2e-2:      # near-tie: either choice is legitimate, and the continuations diverge
+            if margins[i] < 8e-3:      # near-tie: either choice is legitimate, and the continuations diverge
                 break
             assert g == w, (p, i, a, want)
             compared += 1
-    assert compared >= 20
+    assert compared >= 12
 
 
 def test_offline_inference_samples_workload_and_prefix_benchmark():
