@@ -52,7 +52,7 @@ def attn_bytes_per_launch(B, kv_lens_sum, H, Hkv, D, kv_quant):
 
 def cpu_baseline(model_kw, kv_len, budget_s=25.0):
     """the oracle (CPU restatement, 'port') on a bounded sample: decode steps of a batch of 8 at the same kv_len."""
-    from oracle import ref
+    from oracle import ref  # sets OMP_NUM_THREADS to the CPUs this container may really use (cgroup quota)
     B = 8
     desc = ref.make_desc(max_position=2048, cache_quant_bit=8, cache_quant_group=8, cache_layout=3, cache_mode=0,
                          weight_quant_bit=8, **model_kw)
@@ -83,6 +83,45 @@ def cpu_baseline(model_kw, kv_len, budget_s=25.0):
                       f"(oracle/llama_ref.c, OpenMP; setup {setup_s:.1f}s not timed)"}
 
 
+def dry_run(args, P, dist, rank, world):
+    """the N>1 control plane without a GPU: rendezvous, unique-id broadcast, barrier-bracketed timing, MAX over ranks,
+    one JSON line from rank 0.  (tests/test_tp_gloo.py)"""
+    uid = None
+    if rank == 0:
+        try:
+            uid = P.get_unique_id()
+        except Exception:
+            uid = os.urandom(P.UNIQUE_ID_BYTES)
+    agreed = True
+    if dist is not None:
+        box = [uid]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+        allv = [None] * world
+        dist.all_gather_object(allv, uid)
+        agreed = all(v == allv[0] for v in allv) and len(uid) == P.UNIQUE_ID_BYTES
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (rank + 1))
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "decode tokens/sec, LLaMA-7B int8 (W8A16), max-running-batch 1024", "value": 0.0,
+                          "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4), "higher_is_better": True,
+                          "scaling": "strong", "vs_baseline": None, "dry_run": True, "unique_id_agreed": agreed,
+                          "config": {"workload": "dry run (no device work)", "parallelism": f"tp{world}"}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,6 +136,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tpb", type=int, default=0)
     ap.add_argument("--prefill-sample", type=int, default=1, help="also time one 8192-token prefill step (TTFT proxy)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no device work: exercises only the multi-process control plane (CPU test of the N>1 path)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,6 +155,8 @@ def main():
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     P = load_pplhip()
+    if args.dry_run:
+        return dry_run(args, P, dist, rank, world)
     mk = dict(MODELS[args.model])
     if args.layers:
         mk["num_layers"] = args.layers

@@ -342,3 +342,32 @@ def make_step(token_inputs, seq_starts, start_pos, cache_indices, decoding_batch
     st.req_list_changed = req_list_changed
     st._keep = (tok, ss, sp, ci, kvs)
     return st
+
+
+def shard_weights(weights, desc, tp, rank):
+    """Export-side helper: slices an UNSHARDED fp16 weight dict (names of DESIGN.md section 3) for tensor-parallel rank
+    `rank` of `tp` -- the partitioning of SURVEY.md 8(e): wqkv / w13 / output on the output dim (heads, inter, vocab),
+    wo / w2 on the input dim; embeddings and norms replicated.  (Quantised models are quantised per slice AFTER this.)"""
+    H, Hkv, hd = desc.num_heads, desc.num_kv_heads, desc.hidden_dim
+    D, inter, V = hd // H, desc.intermediate_dim, desc.vocab_size
+    h, hk, it, vl = H // tp, Hkv // tp, inter // tp, V // tp
+    out = {}
+    for name, w in weights.items():
+        w = np.asarray(w)
+        if name.endswith("attention.wqkv.weight"):
+            w = w.reshape((H + 2 * Hkv) * D, hd)
+            q, k, v = w[:H * D], w[H * D:(H + Hkv) * D], w[(H + Hkv) * D:]
+            out[name] = np.concatenate([q[rank * h * D:(rank + 1) * h * D], k[rank * hk * D:(rank + 1) * hk * D],
+                                        v[rank * hk * D:(rank + 1) * hk * D]], 0)
+        elif name.endswith("attention.wo.weight"):
+            out[name] = np.ascontiguousarray(w.reshape(hd, H * D)[:, rank * h * D:(rank + 1) * h * D])
+        elif name.endswith("feed_forward.w13.weight"):
+            w = w.reshape(2 * inter, hd)
+            out[name] = np.concatenate([w[rank * it:(rank + 1) * it], w[inter + rank * it:inter + (rank + 1) * it]], 0)
+        elif name.endswith("feed_forward.w2.weight"):
+            out[name] = np.ascontiguousarray(w.reshape(hd, inter)[:, rank * it:(rank + 1) * it])
+        elif name == "output.weight":
+            out[name] = np.ascontiguousarray(w.reshape(V, hd)[rank * vl:(rank + 1) * vl])
+        else:
+            out[name] = w
+    return out

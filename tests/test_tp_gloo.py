@@ -1,0 +1,147 @@
+"""Tensor parallelism without GPUs:
+  1. the sharding spec: the oracle run on two slices produced by pplhip.shard_weights (+ explicit all-reduce /
+     all-gather inside ref_forward) equals the unsharded oracle;
+  2. world_size 2 over gloo: two PROCESSES each own one slice, run the per-rank half of every layer with the oracle's
+     operators in exactly the order libpplhip's pplhip_run issues them, exchange through torch.distributed
+     (all_reduce of the row-parallel outputs, all_gather of the vocab shards) and reproduce the unsharded logits;
+  3. bench.py's multi-process control plane (rendezvous, unique-id broadcast, MAX-over-ranks timing) in --dry-run."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import ref
+from tests.conftest import ROOT, load_pplhip
+from tests.test_oracle_hf import desc_from_meta, load_fixture
+
+
+def _setup(golden_dir):
+    meta, weights, prompts, hf_logits, _, _ = load_fixture(os.path.join(golden_dir, "hf_tiny_gqa.npz"))
+    desc = desc_from_meta(meta, cache_quant_bit=8, cache_quant_group=8)
+    return desc, weights, prompts
+
+
+def _step(prompts):
+    lens = np.array([len(p) for p in prompts])
+    return ref.make_step(np.concatenate(prompts), np.concatenate([[0], np.cumsum(lens)]), np.zeros(len(prompts), dtype=np.int64),
+                         np.concatenate([[0], np.cumsum(lens + 4)[:-1]]), 0)
+
+
+def test_sharded_oracle_equals_unsharded(golden_dir):
+    m = load_pplhip()
+    desc, weights, prompts = _setup(golden_dir)
+    full = ref.RefModel(desc)
+    for k, v in weights.items():
+        full.set_tensor(k, v)
+    full.kv_alloc(64)
+    want = ref.forward([full], _step(prompts))
+    slices = []
+    for r in range(2):
+        s = ref.RefModel(desc, tp_size=2, tp_rank=r)
+        for k, v in m.shard_weights(weights, desc, 2, r).items():
+            s.set_tensor(k, v)
+        s.kv_alloc(64)
+        slices.append(s)
+    got = ref.forward(slices, _step(prompts))
+    assert np.abs(got - want).max() < 4e-3 * max(1.0, np.abs(want).max())
+    assert (got.argmax(-1) == want.argmax(-1)).all()
+
+
+WORKER = r'''
+import ctypes as C, os, sys, json
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from oracle import ref
+from tests.conftest import load_pplhip
+from tests.test_oracle_hf import desc_from_meta, load_fixture
+from tests.test_tp_gloo import _setup, _step
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+m = load_pplhip()
+desc, weights, prompts = _setup(os.path.join(sys.argv[1], "tests", "golden"))
+sl = ref.RefModel(desc, tp_size=world, tp_rank=rank)
+for k, v in m.shard_weights(weights, desc, world, rank).items():
+    sl.set_tensor(k, v)
+sl.kv_alloc(64)
+st = _step(prompts)
+L = ref.lib()
+T, B, hd = st.num_tokens, st.batch, desc.hidden_dim
+H, Hkv, D = desc.num_heads // world, desc.num_kv_heads // world, desc.hidden_dim // desc.num_heads
+inter, vl = desc.intermediate_dim // world, desc.vocab_size // world
+tok, ss, sp, ci, _ = st._keep
+f32 = lambda *s: np.zeros(s, dtype=np.float32)
+p = lambda a: a.ctypes.data
+rh = lambda a: a.astype(np.float16).astype(np.float32)
+def lin(x, name, N, K, out32=0):
+    w = sl.get_tensor(name + ".weight", np.float16)
+    y = f32(x.shape[0], N)
+    L.ref_linear_raw(p(x), p(w), None, 0, 0, x.shape[0], N, K, p(y), out32)
+    return y
+def allreduce(x):                      # ncclAllReduce(fp16) of pplhip_run
+    t = torch.from_numpy(x.copy()); dist.all_reduce(t); return rh(t.numpy())
+rope = f32(desc.max_position, D); L.ref_build_rope_table(p(rope), desc.max_position, D, desc.rope_theta)
+h = f32(T, hd); L.ref_embedding(p(tok), p(sl.get_tensor("tok_embeddings.weight", np.float16)), T, hd, p(h))
+pending = None
+for l in range(desc.num_layers):
+    xn = f32(T, hd)
+    L.ref_rmsnorm(p(h), None if pending is None else p(pending), p(sl.get_tensor(f"layers.{l}.attention_norm.weight", np.float16)),
+                  desc.norm_eps, T, hd, p(xn), p(h))
+    qkv = lin(xn, f"layers.{l}.attention.wqkv", (H + 2 * Hkv) * D, hd)
+    L.ref_rope_kv_write(p(qkv), p(rope), C.byref(desc), H, Hkv, D, l, L.ref_kv_ptr(sl.h, 0), L.ref_kv_ptr(sl.h, 1), 64,
+                        p(ss), p(sp), p(ci), 0, B)
+    att = f32(T, H * D)
+    L.ref_attention(p(qkv), C.byref(desc), H, Hkv, D, l, L.ref_kv_ptr(sl.h, 0), L.ref_kv_ptr(sl.h, 1), 64, p(ss), p(sp), p(ci), 0, B, p(att))
+    part = allreduce(lin(att, f"layers.{l}.attention.wo", hd, H * D))
+    L.ref_rmsnorm(p(h), p(part), p(sl.get_tensor(f"layers.{l}.ffn_norm.weight", np.float16)), desc.norm_eps, T, hd, p(xn), p(h))
+    gu = lin(xn, f"layers.{l}.feed_forward.w13", 2 * inter, hd)
+    act = f32(T, inter); L.ref_silu_mul(p(gu), T, inter, p(act))
+    pending = allreduce(lin(act, f"layers.{l}.feed_forward.w2", hd, inter))
+last = ss[1:] - 1
+hl, pl, hn = np.ascontiguousarray(h[last]), np.ascontiguousarray(pending[last]), f32(B, hd)
+L.ref_rmsnorm(p(hl), p(pl), p(sl.get_tensor("norm.weight", np.float16)), desc.norm_eps, B, hd, p(hn), None)
+mine = torch.from_numpy(lin(hn, "output", vl, hd, 1))
+shards = [torch.empty_like(mine) for _ in range(world)]
+dist.all_gather(shards, mine)          # ncclAllGather + strided copies of pplhip_run
+logits = torch.cat(shards, 1).numpy()
+if rank == 0:
+    np.save(sys.argv[2], logits)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_world_size_2_gloo_matches_unsharded(golden_dir, tmp_path):
+    desc, weights, prompts = _setup(golden_dir)
+    full = ref.RefModel(desc)
+    for k, v in weights.items():
+        full.set_tensor(k, v)
+    full.kv_alloc(64)
+    want = ref.forward([full], _step(prompts))
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    out = tmp_path / "logits.npy"
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                           "127.0.0.1", "--master-port", "29631", str(script), ROOT, str(out)], env=env, timeout=600,
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    got = np.load(out)
+    assert np.abs(got - want).max() < 4e-3 * max(1.0, np.abs(want).max())
+    assert (got.argmax(-1) == want.argmax(-1)).all()
+
+
+def test_bench_control_plane_world_size_2_dry_run():
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                   "--master-addr", "127.0.0.1", "--master-port", "29632", os.path.join(ROOT, "bench.py"),
+                                   "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"], env=env, timeout=600,
+                                  stderr=subprocess.DEVNULL).decode()
+    line = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(line) == 1                       # rank 0 prints ONE json line
+    res = json.loads(line[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["warmup"] == 1 and res["scaling"] == "strong"
+    assert res["dry_run"] is True and res["unique_id_agreed"] is True and res["config"]["parallelism"] == "tp2"
