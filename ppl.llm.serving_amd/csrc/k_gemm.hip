@@ -14,6 +14,8 @@
 //   to all of them; MI355X_MICROARCH: block b -> XCD b % 8).
 // Numerics: fp32 accumulate; W8: y = scale[n] * sum (exact int8 -> fp16); W4: fp16(q * scale) per element
 // (one rounding).  Oracle: ref_linear_fwd (oracle/llama_ref.c).
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace pplhip {
@@ -192,6 +194,182 @@ __global__ __launch_bounds__(256) void gemm_kernel(const uint16_t* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// W8A16 fast path (K % 64 == 0): both operands go global -> LDS by DMA (global_load_lds_dwordx4: no staging VGPRs, no
+// ds_write pass), the weight tile stays int8 in LDS (half the LDS bytes and half the fragment-read bytes) and is
+// converted to fp16 in registers right before the MFMA (exact: x ^ 0x80 -> 0x6400 | u8 -> minus 1152, two VALU ops per
+// pair, in the shadow of the matrix pipe).  Two LDS stages, one barrier per K tile: the DMA of tile t+1 is issued
+// right after the barrier that publishes tile t and lands during the MFMAs of tiles t and t+1 (3-stage ring).
+// The DMA writes LDS linearly (wave-uniform base + lane * 16 B), so the XOR swizzle is applied to the per-lane SOURCE
+// address and again on the fragment reads (cdna_hip_programming.md rule 21).
+// ---------------------------------------------------------------------------------------------------------------
+// 16-byte chunk swizzle of the int8 weight tile (64-byte rows, 4 rows per 256-byte bank window): conflict-free for
+// the four 16-lane groups ds_read_b128 is serviced in ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ... -- MI355X_MICROARCH LDS)
+__device__ __forceinline__ int w_swz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
+
+__device__ __forceinline__ h8 cvt_i8x8_f16(uint2 v) {
+    const uint32_t w0 = v.x ^ 0x80808080u, w1 = v.y ^ 0x80808080u;
+    const h2 bias = {(_Float16)1152.0f, (_Float16)1152.0f};
+    const h2 a = __builtin_bit_cast(h2, __builtin_amdgcn_perm(0x64646464u, w0, 0x04010400u)) - bias;
+    const h2 b = __builtin_bit_cast(h2, __builtin_amdgcn_perm(0x64646464u, w0, 0x04030402u)) - bias;
+    const h2 c = __builtin_bit_cast(h2, __builtin_amdgcn_perm(0x64646464u, w1, 0x04010400u)) - bias;
+    const h2 d = __builtin_bit_cast(h2, __builtin_amdgcn_perm(0x64646464u, w1, 0x04030402u)) - bias;
+    return h8{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+}
+
+// LDS-DMA issued from inline asm so that hipcc does not see an outstanding LDS write and does not drain vmcnt(0)
+// in front of the fragment reads of the CURRENT tile (cdna_hip_programming.md 5.7: M0 is written and restored in the
+// same statement; completion is waited for by hand with s_waitcnt vmcnt(0) before the publishing barrier).
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_wave_base /* wave-uniform LDS byte address */) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_wave_base)
+                 : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+
+template <bool OUT32, int G_ST>
+__global__ __launch_bounds__(256) void gemm_w8_dma_kernel(const uint16_t* __restrict__ x, const int8_t* __restrict__ w,
+                                                             const uint16_t* __restrict__ scale, int64_t M, int N, int K,
+                                                             void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles,
+                                                             int map_mode) {
+    // ONE __shared__ object (a second one makes hipcc wait vmcnt(0) before every ds_read of a DMA pipeline)
+    __shared__ __attribute__((aligned(16))) char smem[G_ST * (G_BM * G_BK * 2 + G_BN * G_BK)];  // per stage: X 16 KiB + W 8 KiB
+    uint16_t* const Xs0 = reinterpret_cast<uint16_t*>(smem);
+    int8_t* const Wq0 = reinterpret_cast<int8_t*>(smem + G_ST * G_BM * G_BK * 2);
+
+    // block -> tile.  map_mode 1 (m_tiles % 8 == 0): XCD x = id % 8 owns the activation row-tiles m == x (mod 8) and
+    // walks all weight tiles, so its 4 MiB L2 keeps that 1 MiB activation slice resident for the whole GEMM and the
+    // weights stream through once per XCD.  map_mode 0: XCD x owns weight tiles n == x (mod 8) and walks all m tiles.
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    int nt, mt;
+    if (map_mode == 1) {
+        const int mg = m_tiles >> 3;
+        mt = xcd + 8 * (slot % mg);
+        nt = slot / mg;
+    } else {
+        nt = xcd + 8 * (slot / m_tiles);
+        mt = slot % m_tiles;
+    }
+    if (nt >= n_tiles) return;
+    const int n0 = nt * G_BN;
+    const int64_t m0 = (int64_t)mt * G_BM;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int wn = wave >> 1, wm = wave & 1;
+
+    // per-lane DMA sources (constant over K except for the k0 term)
+    const uint16_t* xsrc[4];
+    const int8_t* wsrc[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // LDS position pos = ks*4 + kq of a row holds the source chunk kq*2 + ks, i.e. k = kq*16 + ks*8 .. +8: lane
+        // (ks, kq) then multiplies exactly the k range that ONE 16-byte read of the int8 weight row (chunk kq) delivers
+        const int p = j * 256 + tid, row = p >> 3, pos = (p & 7) ^ ((row >> 1) & 7);
+        const int c = ((pos & 3) << 1) | (pos >> 2);
+        int64_t m = m0 + row;
+        if (m >= M) m = M - 1;  // rows past M are never stored
+        xsrc[j] = x + m * K + c * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = j * 256 + tid, row = p >> 2, c = (p & 3) ^ w_swz(row);
+        int n = n0 + row;
+        if (n >= N) n = N - 1;
+        wsrc[j] = w + (int64_t)n * K + c * 16;
+    }
+    // wave-uniform LDS destinations (byte addresses): piece j of this wave starts at (j * 256 + wave * 64) * 16
+    const uint32_t xdst = __builtin_amdgcn_readfirstlane(lds_addr(Xs0) + wave * 1024);
+    const uint32_t wdst = __builtin_amdgcn_readfirstlane(lds_addr(Wq0) + wave * 1024);
+    auto issue = [&](int stage, int k0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(xsrc[j] + k0, xdst + stage * (G_BM * G_BK * 2) + j * 4096);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(wsrc[j] + k0, wdst + stage * (G_BN * G_BK) + j * 4096);
+    };
+
+    f4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    // G_ST-stage ring, prefetch distance D = G_ST - 1: while tile t is multiplied, tiles t+1 .. t+D are in flight.  Every
+    // wave issues 6 DMA instructions per tile, so "all but the newest 6*j have landed" (vmcnt(6*j)) == tile t is complete
+    // when j younger tiles have been issued.
+    constexpr int D = G_ST - 1;
+    const int ktiles = K / G_BK;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < ktiles) issue(d, d * G_BK);
+    int st = 0, stn = D;  // stage of tile t, stage of tile t+D
+    for (int t = 0; t < ktiles; ++t) {
+        const int younger = (ktiles - 1 - t) < (D - 1) ? (ktiles - 1 - t) : (D - 1);
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // tile t is published; the stage read during iteration t-1 (== stage of tile t+D) is free
+        if (t + D < ktiles) issue(stn, (t + D) * G_BK);
+        const uint16_t* xs = Xs0 + st * (G_BM * G_BK);
+        const int8_t* wq = Wq0 + st * (G_BN * G_BK);
+        st = st == G_ST - 1 ? 0 : st + 1;
+        stn = stn == G_ST - 1 ? 0 : stn + 1;
+        // one 16-byte read per weight row delivers the int8 operands of BOTH k-steps of this lane (k = kq*16 .. +16)
+        uint4 wraw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wn * 64 + i * 16 + l15;
+            wraw[i] = *reinterpret_cast<const uint4*>(&wq[row * G_BK + (kq ^ w_swz(row)) * 16]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            h8 a[4], bfr[4];
+#pragma unroll
+#ifdef PPLHIP_ABL_NOCVT  // ablation only (wrong numerics): what the int8 -> fp16 conversion costs
+            for (int i = 0; i < 4; ++i) a[i] = __builtin_bit_cast(h8, ks == 0 ? make_uint4(wraw[i].x, wraw[i].y, wraw[i].x, wraw[i].y) : make_uint4(wraw[i].z, wraw[i].w, wraw[i].z, wraw[i].w));
+#else
+            for (int i = 0; i < 4; ++i) a[i] = cvt_i8x8_f16(ks == 0 ? make_uint2(wraw[i].x, wraw[i].y) : make_uint2(wraw[i].z, wraw[i].w));
+#endif
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wm * 64 + j * 16 + l15;
+                bfr[j] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&xs[row * G_BK + g_swz(row, ks * 4 + kq) * 8]));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + kq * 4;
+        if (n >= N) continue;
+        const h4 sh = __builtin_bit_cast(h4, *reinterpret_cast<const uint2*>(scale + n));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t m = m0 + wm * 64 + j * 16 + l15;
+            if (m >= M) continue;
+            if constexpr (OUT32) {
+                float4 o = make_float4(acc[i][j][0] * (float)sh[0], acc[i][j][1] * (float)sh[1], acc[i][j][2] * (float)sh[2],
+                                       acc[i][j][3] * (float)sh[3]);
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(yv) + m * ldy + n) = o;
+            } else {
+                h4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (_Float16)(acc[i][j][r] * (float)sh[r]);
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(yv) + m * ldy + n) = __builtin_bit_cast(uint2, o);
+            }
+        }
+    }
+}
+
 hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const uint16_t* scale, int wq_bit, int group,
                          int64_t M, int N, int K, void* y, int64_t ldy, bool out_fp32) {
     if (M == 0) return hipSuccess;
@@ -203,6 +381,23 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
     const int m_tiles = (int)((M + G_BM - 1) / G_BM);
     const int n_tiles_pad = (n_tiles + 7) / 8 * 8;
     dim3 grid((unsigned)(n_tiles_pad * m_tiles)), block(256);
+    if (wq_bit == 8 && K % G_BK == 0 && !getenv("PPLHIP_GEMM_GENERIC")) {
+        static const int forced = getenv("PPLHIP_GEMM_MAP") ? atoi(getenv("PPLHIP_GEMM_MAP")) : -1;
+        int map_mode = (m_tiles % 8 == 0) ? 1 : 0;
+        if (forced == 0) map_mode = 0;
+        dim3 g2 = map_mode == 1 ? dim3((unsigned)(n_tiles * m_tiles)) : grid;
+        static const int forced_st = getenv("PPLHIP_GEMM_STAGES") ? atoi(getenv("PPLHIP_GEMM_STAGES")) : 0;
+        // few blocks per CU -> deeper ring (latency is hidden inside the block); many -> more blocks per CU
+        int stages = (int64_t)n_tiles * m_tiles <= 256 ? 4 : 2;  // measured: profiles/gemm_microbench.py
+        if (forced_st >= 2 && forced_st <= 4) stages = forced_st;
+#define W8_LAUNCH(O32, ST)                                                                                            \
+    hipLaunchKernelGGL((gemm_w8_dma_kernel<O32, ST>), g2, block, 0, s, x, (const int8_t*)w, scale, M, N, K, y, ldy,   \
+                       n_tiles, m_tiles, map_mode)
+        if (out_fp32) { if (stages == 2) W8_LAUNCH(true, 2); else if (stages == 3) W8_LAUNCH(true, 3); else W8_LAUNCH(true, 4); }
+        else { if (stages == 2) W8_LAUNCH(false, 2); else if (stages == 3) W8_LAUNCH(false, 3); else W8_LAUNCH(false, 4); }
+#undef W8_LAUNCH
+        return hipGetLastError();
+    }
 #define GEMM_CASE(WQ, O32)                                                                                          \
     if (wq_bit == WQ && out_fp32 == O32) {                                                                          \
         hipLaunchKernelGGL((gemm_kernel<WQ, O32>), grid, block, 0, s, x, w, scale, M, N, K, group, y, ldy, n_tiles, \
