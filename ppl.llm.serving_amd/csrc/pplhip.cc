@@ -206,8 +206,9 @@ int decode_split(const pplhip_ctx* c, int64_t nb, int64_t max_kv_len) {
     if (mode == 0) return 1;
     const int64_t blocks = nb * c->H;
     int split = 1;
-    if (mode == 2 || (blocks < 1024 && max_kv_len >= 1024)) {
-        int64_t want = (2048 + blocks - 1) / blocks;           // aim for >= 2048 workgroups
+    // measured (profiles/attn_microbench.py): 512 workgroups already stream at 5.3 TB/s; split only below ~256
+    if (mode == 2 || (blocks < 256 && max_kv_len >= 512)) {
+        int64_t want = (512 + blocks - 1) / blocks;            // aim for >= 512 workgroups
         int64_t cap = std::max<int64_t>(1, max_kv_len / 256);  // >= 256 tokens per split
         split = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want, cap), 32));
         if (mode == 2 && split < 2 && max_kv_len >= 64) split = 2;

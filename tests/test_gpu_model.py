@@ -184,3 +184,48 @@ def test_prefix_cache_hit_equals_cold_prefill():
     assert np.abs(cold - hit).max() <= 2e-3 * max(1.0, np.abs(cold).max())
     assert cold.argmax() == hit.argmax()
     ctx.close()
+
+
+def test_penalty_and_sampling_through_the_abi():
+    """K12: repetition / presence / frequency penalties + temperature on the logits of a real step, count map kept
+    across steps per batch slot (src/backends/cuda/post_processor.cc:221-281), against ref_penalty."""
+    import ctypes as C
+    m = load_pplhip()
+    desc = ref.make_desc(hidden_dim=256, intermediate_dim=512, num_layers=1, num_heads=4, num_kv_heads=4, vocab_size=1024,
+                         max_position=256, cache_quant_bit=0, cache_quant_group=1, cache_layout=3, cache_mode=0)
+    ctx = m.Context(m.copy_desc(desc), max_running_batch=8, max_tokens_per_step=64, enable_penalty=True)
+    ctx.init_synthetic(0, 3)
+    ctx.kv_alloc(0, 256)
+    rng = np.random.RandomState(2)
+    prompts = [rng.randint(3, 1024, size=n) for n in (12, 5, 9)]
+    n = len(prompts)
+    lens = np.array([len(p) for p in prompts])
+    slots = np.array([5, 0, 2], dtype=np.int64)
+    temps = np.array([0.7, 1.0, 1.3], dtype=np.float32)
+    rep = np.array([1.2, 1.0, 1.5], dtype=np.float32)
+    pres = np.array([0.1, 0.0, 0.3], dtype=np.float32)
+    freq = np.array([0.05, 0.2, 0.0], dtype=np.float32)
+    count_map = np.zeros((8, 1024), dtype=np.uint16)
+    tok = np.concatenate(prompts).astype(np.int64)
+    seq = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    sp = np.zeros(n, dtype=np.int64)
+    ci = np.array([0, 64, 128], dtype=np.int64)
+    for s in range(3):
+        ctx.set_inputs(0, m.make_step(tok, seq, sp, ci, 0 if s == 0 else n, req_list_changed=int(s == 0)))
+        ctx.run(0)
+        raw = ctx.copy_logits(n)
+        ctx.penalty(temps, rep, pres, freq, slots, req_list_changed=(s == 0))
+        got = ctx.copy_logits(n)
+        want = raw.copy()
+        ref.lib().ref_penalty(want.ctypes.data, temps.ctypes.data, rep.ctypes.data, pres.ctypes.data, freq.ctypes.data,
+                              slots.ctypes.data, tok.ctypes.data, seq.ctypes.data, sp.ctypes.data, n, 1024, count_map.ctypes.data)
+        assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+        gtok, _ = ctx.sample(n, top_k=1, temperatures=temps, enable_penalty=True, req_list_changed=(s == 0))
+        wtok, _ = ref.sample(want, top_k=1)
+        srt = np.sort(want, -1)
+        safe = (srt[:, -1] - srt[:, -2]) > 1e-4
+        assert (gtok[safe] == wtok[safe]).all()
+        sp = sp + (seq[1:] - seq[:-1])
+        tok = wtok.astype(np.int64)
+        seq = np.arange(n + 1, dtype=np.int64)
+    ctx.close()
