@@ -370,6 +370,127 @@ __global__ __launch_bounds__(256) void gemm_w8_dma_kernel(const uint16_t* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Skinny path, M <= 32 rows (decode at small batch): HBM-bound -- every weight byte is read exactly once, straight
+// into registers (no LDS round trip: nothing is shared between waves), with several 16-byte loads per lane in flight.
+//   grid = N / 16 weight-row tiles; block = 4 waves = 4 contiguous K slices of that tile, summed through LDS;
+//   a wave-load fetches 16 rows x 64 contiguous bytes; lane (row = lane & 15, kq = lane >> 4) multiplies its 16 bytes
+//   (int8: 16 k, two MFMA k-steps; fp16: 8 k; int4: 32 k, four k-steps) against the matching activation fragment
+//   (activations are tiny and L1/L2 resident); up to MT = 2 row tiles of 16 activations reuse each weight fragment.
+// ---------------------------------------------------------------------------------------------------------------
+template <int WQ, int MT, bool OUT32, int NW>
+__global__ __launch_bounds__(NW * 64) void gemv_kernel(const uint16_t* __restrict__ x, const void* __restrict__ wv,
+                                                   const uint16_t* __restrict__ scale, int64_t M, int N, int K, int group,
+                                                   void* __restrict__ yv, int64_t ldy) {
+    constexpr int KL = WQ == 8 ? 16 : (WQ == 4 ? 32 : 8);  // k elements in one lane's 16 bytes
+    constexpr int KSTEP = KL * 4;                          // k elements per wave-load
+    constexpr int NKS = KL / 8;                            // MFMA k-steps per load
+    __shared__ __attribute__((aligned(16))) float red[NW - 1][MT][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    int n = n0 + l15;
+    if (n >= N) n = N - 1;
+    const int steps = (K + KSTEP - 1) / KSTEP;
+    const int per = (steps + NW - 1) / NW;
+    const int s_begin = wave * per, s_end = (s_begin + per < steps) ? s_begin + per : steps;
+    const char* wrow = reinterpret_cast<const char*>(wv) + ((int64_t)n * K * (WQ == 0 ? 16 : WQ)) / 8;
+    const uint16_t* xrow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int64_t m = mt * 16 + l15;
+        if (m >= M) m = M - 1;
+        xrow[mt] = x + m * K;
+    }
+    f4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 4
+    for (int st = s_begin; st < s_end; ++st) {
+        const int k = st * KSTEP + kq * KL;
+        const bool ok = k < K;  // K is a multiple of KL (checked by the launcher)
+        const uint4 wr = ok ? *reinterpret_cast<const uint4*>(wrow + ((int64_t)k * (WQ == 0 ? 16 : WQ)) / 8) : make_uint4(0, 0, 0, 0);
+        float wsc = 1.f;
+        if constexpr (WQ == 4) wsc = ok ? h2f(scale[(int64_t)n * (K / group) + k / group]) : 0.f;
+        const uint32_t w4[4] = {wr.x, wr.y, wr.z, wr.w};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            h8 a;
+            if constexpr (WQ == 0) {
+                a = __builtin_bit_cast(h8, wr);
+            } else if constexpr (WQ == 8) {
+                a = cvt_i8x8_f16(make_uint2(w4[ks * 2], w4[ks * 2 + 1]));
+            } else {
+                const uint32_t word = w4[ks];  // 8 nibbles, low nibble = even k
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] = (_Float16)((float)((int)((word >> (4 * e)) & 15u) - 8) * wsc);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const uint4 xr = ok ? *reinterpret_cast<const uint4*>(xrow[mt] + k + ks * 8) : make_uint4(0, 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, xr), acc[mt], 0, 0, 0);
+            }
+        }
+    }
+    // sum the NW K slices
+    if (wave > 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f4*>(red[wave - 1][mt][lane]) = acc[mt];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int nn = n0 + kq * 4;
+        if (nn < N) {
+            float sc[4] = {1.f, 1.f, 1.f, 1.f};
+            if constexpr (WQ == 8) {
+                const h4 sh = __builtin_bit_cast(h4, *reinterpret_cast<const uint2*>(scale + nn));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sc[r] = (float)sh[r];
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f4 v = acc[mt];
+#pragma unroll
+                for (int w = 0; w < NW - 1; ++w) {
+                    const f4 o = *reinterpret_cast<const f4*>(red[w][mt][lane]);
+                    v += o;
+                }
+                const int64_t m = mt * 16 + l15;
+                if (m >= M) continue;
+                if constexpr (OUT32) {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(yv) + m * ldy + nn) =
+                        make_float4(v[0] * sc[0], v[1] * sc[1], v[2] * sc[2], v[3] * sc[3]);
+                } else {
+                    h4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (_Float16)(v[r] * sc[r]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(yv) + m * ldy + nn) = __builtin_bit_cast(uint2, o);
+                }
+            }
+        }
+    }
+}
+
+template <int WQ, bool OUT32>
+static hipError_t launch_gemv(hipStream_t s, const uint16_t* x, const void* w, const uint16_t* scale, int group, int64_t M,
+                              int N, int K, void* y, int64_t ldy) {
+    dim3 grid((unsigned)((N + 15) / 16));
+    const int mt = (int)((M + 15) / 16);
+    static const int forced_nw = getenv("PPLHIP_GEMV_WAVES") ? atoi(getenv("PPLHIP_GEMV_WAVES")) : 0;
+    // up to 1024 row tiles -> 8 K slices per tile so that every CU has enough waves streaming (profiles/gemm_microbench.py)
+    const int nw = forced_nw ? forced_nw : ((N + 15) / 16 <= 1024 ? 8 : 4);
+#define GEMV_CASE(MT)                                                                                                    \
+    if (mt == MT) {                                                                                                      \
+        if (nw == 8) hipLaunchKernelGGL((gemv_kernel<WQ, MT, OUT32, 8>), grid, dim3(512), 0, s, x, w, scale, M, N, K, group, y, ldy); \
+        else hipLaunchKernelGGL((gemv_kernel<WQ, MT, OUT32, 4>), grid, dim3(256), 0, s, x, w, scale, M, N, K, group, y, ldy);       \
+        return hipGetLastError();                                                                                        \
+    }
+    GEMV_CASE(1) GEMV_CASE(2)
+#undef GEMV_CASE
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const uint16_t* scale, int wq_bit, int group,
                          int64_t M, int N, int K, void* y, int64_t ldy, bool out_fp32) {
     if (M == 0) return hipSuccess;
@@ -377,6 +498,14 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
     if (wq_bit == 0 && K % 8) return hipErrorInvalidValue;
     if (wq_bit == 8 && K % 16) return hipErrorInvalidValue;
     if (wq_bit == 4 && (K % 32 || group % 32 || K % group)) return hipErrorInvalidValue;
+    if (M <= 32 && !getenv("PPLHIP_GEMM_NOSKINNY")) {  // above 32 rows the tiled kernel is faster (profiles/gemm_microbench.py)
+#define GEMV_DISPATCH(WQ)                                                                                      \
+    if (wq_bit == WQ)                                                                                          \
+        return out_fp32 ? launch_gemv<WQ, true>(s, x, w, scale, group, M, N, K, y, ldy)                        \
+                        : launch_gemv<WQ, false>(s, x, w, scale, group, M, N, K, y, ldy);
+        GEMV_DISPATCH(0) GEMV_DISPATCH(8) GEMV_DISPATCH(4)
+#undef GEMV_DISPATCH
+    }
     const int n_tiles = (N + G_BN - 1) / G_BN;
     const int m_tiles = (int)((M + G_BM - 1) / G_BM);
     const int n_tiles_pad = (n_tiles + 7) / 8 * 8;
