@@ -444,8 +444,8 @@ REF_API void ref_silu_mul(const float* gate_up, int64_t T, int inter, float* out
 
 /* K4+K5: RoPE (half-split pairing (i, i+D/2), HF convention) on q and k, then write k,v to the cache.
  * Position of row t of request b: start_pos[b] + (t - seq_starts[b])  (llm_generator.cc:263-298).
- * int8 KV, per group of `g` channels: scale = fp16(max|x| / 127); q = clamp(rint(x / fp32(scale)), -127, 127);
- * scale == 0 -> q = 0. */
+ * int8 KV, per group of `g` channels: scale = fp16(max|x| / 127); inv = 1 / fp32(scale) (correctly rounded, 0 when
+ * scale == 0); q = clamp(rint(x * inv), -127, 127). */
 REF_API void ref_rope_kv_write(float* qkv, const float* rope, const ref_model_desc* d, int H, int Hkv, int D, int layer,
                                void* kv_cache, f16* kv_scale, int64_t kv_tokens, const int64_t* seq_starts,
                                const int64_t* start_pos, const int64_t* cache_indices, int64_t max_pages, int64_t B) {
@@ -484,8 +484,9 @@ REF_API void ref_rope_kv_write(float* qkv, const float* rope, const ref_model_de
                             const f16 sh = f2h(mx / 127.0f);
                             const float sf = h2f(sh);
                             kv_scale[sbase + gi] = sh;
+                            const float inv = sf > 0 ? 1.0f / sf : 0.0f;
                             for (int i = 0; i < g; ++i) {
-                                float qv = sf > 0 ? rintf(x[gi * g + i] / sf) : 0.0f;
+                                float qv = rintf(x[gi * g + i] * inv);
                                 qv = fminf(fmaxf(qv, -127.0f), 127.0f);
                                 ((int8_t*)kv_cache)[base + gi * g + i] = (int8_t)qv;
                             }

@@ -231,15 +231,19 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
 
-template <bool OUT32, int G_ST>
-__global__ __launch_bounds__(256) void gemm_w8_dma_kernel(const uint16_t* __restrict__ x, const int8_t* __restrict__ w,
+template <int WQ, bool OUT32, int G_ST>  // WQ = 8: int8 weights + per-channel scale; WQ = 0: fp16 weights
+__global__ __launch_bounds__(256) void gemm_dma_kernel(const uint16_t* __restrict__ x, const void* __restrict__ wv,
                                                              const uint16_t* __restrict__ scale, int64_t M, int N, int K,
                                                              void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles,
                                                              int map_mode) {
     // ONE __shared__ object (a second one makes hipcc wait vmcnt(0) before every ds_read of a DMA pipeline)
-    __shared__ __attribute__((aligned(16))) char smem[G_ST * (G_BM * G_BK * 2 + G_BN * G_BK)];  // per stage: X 16 KiB + W 8 KiB
+    constexpr int WB = WQ == 8 ? 1 : 2;                 // bytes per weight element
+    constexpr int W_STAGE = G_BN * G_BK * WB;           // 8 KiB (int8) / 16 KiB (fp16)
+    constexpr int W_DMA = W_STAGE / 4096;               // DMA instructions per wave per tile for W
+    __shared__ __attribute__((aligned(16))) char smem[G_ST * (G_BM * G_BK * 2 + W_STAGE)];  // per stage: X 16 KiB + W
     uint16_t* const Xs0 = reinterpret_cast<uint16_t*>(smem);
-    int8_t* const Wq0 = reinterpret_cast<int8_t*>(smem + G_ST * G_BM * G_BK * 2);
+    char* const Wq0 = smem + G_ST * G_BM * G_BK * 2;
+    const char* w = reinterpret_cast<const char*>(wv);
 
     // block -> tile.  map_mode 1 (m_tiles % 8 == 0): XCD x = id % 8 owns the activation row-tiles m == x (mod 8) and
     // walks all weight tiles, so its 4 MiB L2 keeps that 1 MiB activation slice resident for the whole GEMM and the
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(256) void gemm_w8_dma_kernel(const uint16_t* __rest
 
     // per-lane DMA sources (constant over K except for the k0 term)
     const uint16_t* xsrc[4];
-    const int8_t* wsrc[2];
+    const char* wsrc[W_DMA];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         // LDS position pos = ks*4 + kq of a row holds the source chunk kq*2 + ks, i.e. k = kq*16 + ks*8 .. +8: lane
@@ -277,11 +281,20 @@ __global__ __launch_bounds__(256) void gemm_w8_dma_kernel(const uint16_t* __rest
         xsrc[j] = x + m * K + c * 8;
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int p = j * 256 + tid, row = p >> 2, c = (p & 3) ^ w_swz(row);
-        int n = n0 + row;
-        if (n >= N) n = N - 1;
-        wsrc[j] = w + (int64_t)n * K + c * 16;
+    for (int j = 0; j < W_DMA; ++j) {
+        const int p = j * 256 + tid;
+        if constexpr (WQ == 8) {
+            const int row = p >> 2, c = (p & 3) ^ w_swz(row);
+            int n = n0 + row;
+            if (n >= N) n = N - 1;
+            wsrc[j] = w + (int64_t)n * K + c * 16;
+        } else {  // fp16 weights: staged exactly like the activation tile
+            const int row = p >> 3, pos = (p & 7) ^ ((row >> 1) & 7);
+            const int c = ((pos & 3) << 1) | (pos >> 2);
+            int n = n0 + row;
+            if (n >= N) n = N - 1;
+            wsrc[j] = w + ((int64_t)n * K + c * 8) * 2;
+        }
     }
     // wave-uniform LDS destinations (byte addresses): piece j of this wave starts at (j * 256 + wave * 64) * 16
     const uint32_t xdst = __builtin_amdgcn_readfirstlane(lds_addr(Xs0) + wave * 1024);
@@ -290,7 +303,7 @@ __global__ __launch_bounds__(256) void gemm_w8_dma_kernel(const uint16_t* __rest
 #pragma unroll
         for (int j = 0; j < 4; ++j) glds16(xsrc[j] + k0, xdst + stage * (G_BM * G_BK * 2) + j * 4096);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) glds16(wsrc[j] + k0, wdst + stage * (G_BN * G_BK) + j * 4096);
+        for (int j = 0; j < W_DMA; ++j) glds16(wsrc[j] + k0 * WB, wdst + stage * W_STAGE + j * 4096);
     };
 
     f4 acc[4][4];
@@ -310,31 +323,42 @@ __global__ __launch_bounds__(256) void gemm_w8_dma_kernel(const uint16_t* __rest
     int st = 0, stn = D;  // stage of tile t, stage of tile t+D
     for (int t = 0; t < ktiles; ++t) {
         const int younger = (ktiles - 1 - t) < (D - 1) ? (ktiles - 1 - t) : (D - 1);
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (WQ == 8) {  // 6 DMA instructions per wave per tile
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {                  // 8 per tile
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();  // tile t is published; the stage read during iteration t-1 (== stage of tile t+D) is free
         if (t + D < ktiles) issue(stn, (t + D) * G_BK);
         const uint16_t* xs = Xs0 + st * (G_BM * G_BK);
-        const int8_t* wq = Wq0 + st * (G_BN * G_BK);
+        const char* wq = Wq0 + st * W_STAGE;
         st = st == G_ST - 1 ? 0 : st + 1;
         stn = stn == G_ST - 1 ? 0 : stn + 1;
         // one 16-byte read per weight row delivers the int8 operands of BOTH k-steps of this lane (k = kq*16 .. +16)
         uint4 wraw[4];
+        if constexpr (WQ == 8) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = wn * 64 + i * 16 + l15;
-            wraw[i] = *reinterpret_cast<const uint4*>(&wq[row * G_BK + (kq ^ w_swz(row)) * 16]);
+            for (int i = 0; i < 4; ++i) {
+                const int row = wn * 64 + i * 16 + l15;
+                wraw[i] = *reinterpret_cast<const uint4*>(&wq[row * G_BK + (kq ^ w_swz(row)) * 16]);
+            }
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             h8 a[4], bfr[4];
 #pragma unroll
-#ifdef PPLHIP_ABL_NOCVT  // ablation only (wrong numerics): what the int8 -> fp16 conversion costs
-            for (int i = 0; i < 4; ++i) a[i] = __builtin_bit_cast(h8, ks == 0 ? make_uint4(wraw[i].x, wraw[i].y, wraw[i].x, wraw[i].y) : make_uint4(wraw[i].z, wraw[i].w, wraw[i].z, wraw[i].w));
-#else
-            for (int i = 0; i < 4; ++i) a[i] = cvt_i8x8_f16(ks == 0 ? make_uint2(wraw[i].x, wraw[i].y) : make_uint2(wraw[i].z, wraw[i].w));
-#endif
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (WQ == 8) {
+                    a[i] = cvt_i8x8_f16(ks == 0 ? make_uint2(wraw[i].x, wraw[i].y) : make_uint2(wraw[i].z, wraw[i].w));
+                } else {
+                    const int row = wn * 64 + i * 16 + l15;
+                    a[i] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&wq[(row * G_BK + g_swz(row, ks * 4 + kq) * 8) * 2]));
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = wm * 64 + j * 16 + l15;
@@ -351,7 +375,8 @@ __global__ __launch_bounds__(256) void gemm_w8_dma_kernel(const uint16_t* __rest
     for (int i = 0; i < 4; ++i) {
         const int n = n0 + wn * 64 + i * 16 + kq * 4;
         if (n >= N) continue;
-        const h4 sh = __builtin_bit_cast(h4, *reinterpret_cast<const uint2*>(scale + n));
+        h4 sh = {(_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f};
+        if constexpr (WQ == 8) sh = __builtin_bit_cast(h4, *reinterpret_cast<const uint2*>(scale + n));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t m = m0 + wm * 64 + j * 16 + l15;
@@ -378,6 +403,130 @@ __global__ __launch_bounds__(256) void gemm_w8_dma_kernel(const uint16_t* __rest
 //   (int8: 16 k, two MFMA k-steps; fp16: 8 k; int4: 32 k, four k-steps) against the matching activation fragment
 //   (activations are tiny and L1/L2 resident); up to MT = 2 row tiles of 16 activations reuse each weight fragment.
 // ---------------------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------------
+// W8A16, large M (prefill steps, M >= 4096): 256 x 256 x 64 block tile, 8 waves as 4 (n) x 2 (m), wave tile
+// 64 (n) x 128 (m) = 4 x 8 MFMA tiles.  Same DMA / int8-in-LDS / swizzle scheme as the 128 x 128 kernel, but per MFMA it
+// reads ~40 % fewer LDS bytes and converts half as many weight fragments, and each activation / weight byte fetched
+// from L2 feeds twice the flops.  One block per CU (3-stage ring = 144 KiB LDS), prefetch distance 2.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int H_BN = 256, H_BM = 256, H_ST = 3;
+
+template <bool OUT32>
+__global__ __launch_bounds__(512) void gemm_w8_dma256_kernel(const uint16_t* __restrict__ x, const int8_t* __restrict__ w,
+                                                             const uint16_t* __restrict__ scale, int64_t M, int N, int K,
+                                                             void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem256[];  // H_ST x (X 32 KiB + W 16 KiB)
+    uint16_t* const Xs0 = reinterpret_cast<uint16_t*>(smem256);
+    int8_t* const Wq0 = reinterpret_cast<int8_t*>(smem256 + H_ST * H_BM * G_BK * 2);
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int nt = xcd + 8 * (slot / m_tiles);
+    const int mt = slot % m_tiles;
+    if (nt >= n_tiles) return;
+    const int n0 = nt * H_BN;
+    const int64_t m0 = (int64_t)mt * H_BM;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int wn = wave >> 1, wm = wave & 1;
+
+    const uint16_t* xsrc[4];
+    const int8_t* wsrc[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = j * 512 + tid, row = p >> 3, pos = (p & 7) ^ ((row >> 1) & 7);
+        const int c = ((pos & 3) << 1) | (pos >> 2);
+        int64_t m = m0 + row;
+        if (m >= M) m = M - 1;
+        xsrc[j] = x + m * K + c * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = j * 512 + tid, row = p >> 2, c = (p & 3) ^ w_swz(row);
+        int n = n0 + row;
+        if (n >= N) n = N - 1;
+        wsrc[j] = w + (int64_t)n * K + c * 16;
+    }
+    const uint32_t xdst = __builtin_amdgcn_readfirstlane(lds_addr(Xs0) + wave * 1024);
+    const uint32_t wdst = __builtin_amdgcn_readfirstlane(lds_addr(Wq0) + wave * 1024);
+    auto issue = [&](int stage, int k0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(xsrc[j] + k0, xdst + stage * (H_BM * G_BK * 2) + j * 8192);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(wsrc[j] + k0, wdst + stage * (H_BN * G_BK) + j * 8192);
+    };
+
+    f4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int ktiles = K / G_BK;
+    issue(0, 0);
+    if (ktiles > 1) issue(1, G_BK);
+    int st = 0, stn = 2;
+    for (int t = 0; t < ktiles; ++t) {
+        if (t + 1 < ktiles) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 2 < ktiles) issue(stn, (t + 2) * G_BK);
+        const uint16_t* xs = Xs0 + st * (H_BM * G_BK);
+        const int8_t* wq = Wq0 + st * (H_BN * G_BK);
+        st = st == H_ST - 1 ? 0 : st + 1;
+        stn = stn == H_ST - 1 ? 0 : stn + 1;
+        uint4 wraw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wn * 64 + i * 16 + l15;
+            wraw[i] = *reinterpret_cast<const uint4*>(&wq[row * G_BK + (kq ^ w_swz(row)) * 16]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            h8 a[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = cvt_i8x8_f16(ks == 0 ? make_uint2(wraw[i].x, wraw[i].y) : make_uint2(wraw[i].z, wraw[i].w));
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh) {
+                h8 bfr[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = wm * 128 + (jh * 4 + j) * 16 + l15;
+                    bfr[j] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&xs[row * G_BK + g_swz(row, ks * 4 + kq) * 8]));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][jh * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], bfr[j], acc[i][jh * 4 + j], 0, 0, 0);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + kq * 4;
+        if (n >= N) continue;
+        const h4 sh = __builtin_bit_cast(h4, *reinterpret_cast<const uint2*>(scale + n));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t m = m0 + wm * 128 + j * 16 + l15;
+            if (m >= M) continue;
+            if constexpr (OUT32) {
+                float4 o = make_float4(acc[i][j][0] * (float)sh[0], acc[i][j][1] * (float)sh[1], acc[i][j][2] * (float)sh[2],
+                                       acc[i][j][3] * (float)sh[3]);
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(yv) + m * ldy + n) = o;
+            } else {
+                h4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (_Float16)(acc[i][j][r] * (float)sh[r]);
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(yv) + m * ldy + n) = __builtin_bit_cast(uint2, o);
+            }
+        }
+    }
+}
+
 template <int WQ, int MT, bool OUT32, int NW>
 __global__ __launch_bounds__(NW * 64) void gemv_kernel(const uint16_t* __restrict__ x, const void* __restrict__ wv,
                                                    const uint16_t* __restrict__ scale, int64_t M, int N, int K, int group,
@@ -510,7 +659,24 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
     const int m_tiles = (int)((M + G_BM - 1) / G_BM);
     const int n_tiles_pad = (n_tiles + 7) / 8 * 8;
     dim3 grid((unsigned)(n_tiles_pad * m_tiles)), block(256);
-    if (wq_bit == 8 && K % G_BK == 0 && !getenv("PPLHIP_GEMM_GENERIC")) {
+    static const int min_m256 = getenv("PPLHIP_GEMM_256_MIN_M") ? atoi(getenv("PPLHIP_GEMM_256_MIN_M")) : 4096;  // measured: only pays at M >= 4096
+    if (wq_bit == 8 && K % G_BK == 0 && M >= min_m256 && N >= 1024 && !getenv("PPLHIP_GEMM_GENERIC")) {
+        const int nt2 = (N + H_BN - 1) / H_BN, mt2 = (int)((M + H_BM - 1) / H_BM);
+        const size_t lds = (size_t)H_ST * (H_BM * G_BK * 2 + H_BN * G_BK);
+        dim3 g256((unsigned)((nt2 + 7) / 8 * 8 * mt2));
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)gemm_w8_dma256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute((const void*)gemm_w8_dma256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        if (out_fp32)
+            hipLaunchKernelGGL((gemm_w8_dma256_kernel<true>), g256, dim3(512), lds, s, x, (const int8_t*)w, scale, M, N, K, y, ldy, nt2, mt2);
+        else
+            hipLaunchKernelGGL((gemm_w8_dma256_kernel<false>), g256, dim3(512), lds, s, x, (const int8_t*)w, scale, M, N, K, y, ldy, nt2, mt2);
+        return hipGetLastError();
+    }
+    if ((wq_bit == 8 || wq_bit == 0) && K % G_BK == 0 && !getenv("PPLHIP_GEMM_GENERIC")) {
         static const int forced = getenv("PPLHIP_GEMM_MAP") ? atoi(getenv("PPLHIP_GEMM_MAP")) : -1;
         int map_mode = (m_tiles % 8 == 0) ? 1 : 0;
         if (forced == 0) map_mode = 0;
@@ -519,12 +685,16 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         // few blocks per CU -> deeper ring (latency is hidden inside the block); many -> more blocks per CU
         int stages = (int64_t)n_tiles * m_tiles <= 256 ? 4 : 2;  // measured: profiles/gemm_microbench.py
         if (forced_st >= 2 && forced_st <= 4) stages = forced_st;
-#define W8_LAUNCH(O32, ST)                                                                                            \
-    hipLaunchKernelGGL((gemm_w8_dma_kernel<O32, ST>), g2, block, 0, s, x, (const int8_t*)w, scale, M, N, K, y, ldy,   \
-                       n_tiles, m_tiles, map_mode)
-        if (out_fp32) { if (stages == 2) W8_LAUNCH(true, 2); else if (stages == 3) W8_LAUNCH(true, 3); else W8_LAUNCH(true, 4); }
-        else { if (stages == 2) W8_LAUNCH(false, 2); else if (stages == 3) W8_LAUNCH(false, 3); else W8_LAUNCH(false, 4); }
-#undef W8_LAUNCH
+        if (wq_bit == 0 && stages == 4) stages = 3;  // fp16 weights: 4 x 32 KiB would leave one block per CU anyway
+#define DMA_LAUNCH(WQ, O32, ST)                                                                                     \
+    hipLaunchKernelGGL((gemm_dma_kernel<WQ, O32, ST>), g2, block, 0, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles, \
+                       map_mode)
+#define DMA_STAGES(WQ, O32)                                                                                         \
+    do { if (stages == 2) DMA_LAUNCH(WQ, O32, 2); else if (stages == 3) DMA_LAUNCH(WQ, O32, 3); else DMA_LAUNCH(WQ, O32, 4); } while (0)
+        if (wq_bit == 8) { if (out_fp32) DMA_STAGES(8, true); else DMA_STAGES(8, false); }
+        else { if (out_fp32) DMA_STAGES(0, true); else DMA_STAGES(0, false); }
+#undef DMA_STAGES
+#undef DMA_LAUNCH
         return hipGetLastError();
     }
 #define GEMM_CASE(WQ, O32)                                                                                          \

@@ -23,10 +23,11 @@ __device__ __forceinline__ void store_group8(const KvAddr& kv, int kvsel, int he
         for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fabsf(x[i]));
         const _Float16 sh = (_Float16)(mx / 127.0f);
         const float sf = (float)sh;
+        const float inv = sf > 0.f ? __fdiv_rn(1.0f, sf) : 0.f;  // one correctly rounded reciprocal per group
         uint32_t lo = 0, hi = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float q = sf > 0.f ? rintf(x[i] / sf) : 0.f;
+            float q = rintf(__fmul_rn(x[i], inv));
             q = fminf(fmaxf(q, -127.f), 127.f);
             const uint32_t b = (uint32_t)(int)q & 0xffu;
             if (i < 4) lo |= b << (8 * i); else hi |= b << (8 * (i - 4));
