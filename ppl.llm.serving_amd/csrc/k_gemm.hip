@@ -16,6 +16,8 @@
 // (one rounding).  Oracle: ref_linear_fwd (oracle/llama_ref.c).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace pplhip {
@@ -235,7 +237,7 @@ template <int WQ, bool OUT32, int G_ST>  // WQ = 8: int8 weights + per-channel s
 __global__ __launch_bounds__(256) void gemm_dma_kernel(const uint16_t* __restrict__ x, const void* __restrict__ wv,
                                                              const uint16_t* __restrict__ scale, int64_t M, int N, int K,
                                                              void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles,
-                                                             int map_mode) {
+                                                             int map_mode, int kt_per_split, float* __restrict__ ws) {
     // ONE __shared__ object (a second one makes hipcc wait vmcnt(0) before every ds_read of a DMA pipeline)
     constexpr int WB = WQ == 8 ? 1 : 2;                 // bytes per weight element
     constexpr int W_STAGE = G_BN * G_BK * WB;           // 8 KiB (int8) / 16 KiB (fp16)
@@ -316,10 +318,14 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const uint16_t* __restric
     // wave issues 6 DMA instructions per tile, so "all but the newest 6*j have landed" (vmcnt(6*j)) == tile t is complete
     // when j younger tiles have been issued.
     constexpr int D = G_ST - 1;
-    const int ktiles = K / G_BK;
+    // split-K (small M): blockIdx.y owns K tiles [kt0, kt0 + ktiles) and writes an fp32 partial slab; a reduce kernel
+    // sums the slabs, applies the channel scales and rounds
+    const int kt_all = K / G_BK;
+    const int kt0 = blockIdx.y * kt_per_split;
+    const int ktiles = (kt0 + kt_per_split < kt_all) ? kt_per_split : kt_all - kt0;
 #pragma unroll
     for (int d = 0; d < D; ++d)
-        if (d < ktiles) issue(d, d * G_BK);
+        if (d < ktiles) issue(d, (kt0 + d) * G_BK);
     int st = 0, stn = D;  // stage of tile t, stage of tile t+D
     for (int t = 0; t < ktiles; ++t) {
         const int younger = (ktiles - 1 - t) < (D - 1) ? (ktiles - 1 - t) : (D - 1);
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const uint16_t* __restric
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();  // tile t is published; the stage read during iteration t-1 (== stage of tile t+D) is free
-        if (t + D < ktiles) issue(stn, (t + D) * G_BK);
+        if (t + D < ktiles) issue(stn, (kt0 + t + D) * G_BK);
         const uint16_t* xs = Xs0 + st * (G_BM * G_BK);
         const char* wq = Wq0 + st * W_STAGE;
         st = st == G_ST - 1 ? 0 : st + 1;
@@ -371,6 +377,20 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const uint16_t* __restric
         }
     }
 
+    if (gridDim.y > 1) {  // fp32 partial slab [split][M][N]
+        float* slab = ws + (int64_t)blockIdx.y * M * N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + kq * 4;
+            if (n >= N) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t m = m0 + wm * 64 + j * 16 + l15;
+                if (m < M) *reinterpret_cast<float4*>(slab + m * N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int n = n0 + wn * 64 + i * 16 + kq * 4;
@@ -396,7 +416,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const uint16_t* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Skinny path, M <= 32 rows (decode at small batch): HBM-bound -- every weight byte is read exactly once, straight
+// Skinny path, M <= 16 rows (decode at small batch): HBM-bound -- every weight byte is read exactly once, straight
 // into registers (no LDS round trip: nothing is shared between waves), with several 16-byte loads per lane in flight.
 //   grid = N / 16 weight-row tiles; block = 4 waves = 4 contiguous K slices of that tile, summed through LDS;
 //   a wave-load fetches 16 rows x 64 contiguous bytes; lane (row = lane & 15, kq = lane >> 4) multiplies its 16 bytes
@@ -640,14 +660,40 @@ static hipError_t launch_gemv(hipStream_t s, const uint16_t* x, const void* w, c
     return hipErrorInvalidValue;
 }
 
+// split-K reduce: y[m][n] = (sum_z slab[z][m][n]) * scale[n]  (scale == NULL: 1)
+template <bool OUT32>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int64_t M, int N,
+                                                            const uint16_t* __restrict__ scale, void* __restrict__ yv, int64_t ldy) {
+    const int64_t total = M * (N / 4);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / (N / 4);
+        const int n = (int)(i - m * (N / 4)) * 4;
+        float4 v = *reinterpret_cast<const float4*>(ws + m * N + n);
+        for (int z = 1; z < splits; ++z) {
+            const float4 o = *reinterpret_cast<const float4*>(ws + ((int64_t)z * M + m) * N + n);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        if (scale) {
+            const h4 sh = __builtin_bit_cast(h4, *reinterpret_cast<const uint2*>(scale + n));
+            v.x *= (float)sh[0]; v.y *= (float)sh[1]; v.z *= (float)sh[2]; v.w *= (float)sh[3];
+        }
+        if constexpr (OUT32) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(yv) + m * ldy + n) = v;
+        } else {
+            const h4 o = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(yv) + m * ldy + n) = __builtin_bit_cast(uint2, o);
+        }
+    }
+}
+
 hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const uint16_t* scale, int wq_bit, int group,
-                         int64_t M, int N, int K, void* y, int64_t ldy, bool out_fp32) {
+                         int64_t M, int N, int K, void* y, int64_t ldy, bool out_fp32, float* ws, size_t ws_bytes) {
     if (M == 0) return hipSuccess;
     if (N % 4 || ldy % 4) return hipErrorInvalidValue;
     if (wq_bit == 0 && K % 8) return hipErrorInvalidValue;
     if (wq_bit == 8 && K % 16) return hipErrorInvalidValue;
     if (wq_bit == 4 && (K % 32 || group % 32 || K % group)) return hipErrorInvalidValue;
-    if (M <= 32 && !getenv("PPLHIP_GEMM_NOSKINNY")) {  // above 32 rows the tiled kernel is faster (profiles/gemm_microbench.py)
+    if (M <= 16 && !getenv("PPLHIP_GEMM_NOSKINNY")) {  // above 16 rows the split-K tiled kernel is faster (profiles/gemm_microbench.py)
 #define GEMV_DISPATCH(WQ)                                                                                      \
     if (wq_bit == WQ)                                                                                          \
         return out_fp32 ? launch_gemv<WQ, true>(s, x, w, scale, group, M, N, K, y, ldy)                        \
@@ -686,15 +732,37 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         int stages = (int64_t)n_tiles * m_tiles <= 256 ? 4 : 2;  // measured: profiles/gemm_microbench.py
         if (forced_st >= 2 && forced_st <= 4) stages = forced_st;
         if (wq_bit == 0 && stages == 4) stages = 3;  // fp16 weights: 4 x 32 KiB would leave one block per CU anyway
+        // split-K for small M: too few output tiles to pull HBM bandwidth (weights must stream at full rate)
+        const int kt_all = K / G_BK;
+        int splits = 1;
+        static const int forced_split = getenv("PPLHIP_GEMM_SPLITK") ? atoi(getenv("PPLHIP_GEMM_SPLITK")) : 0;
+        const int64_t tiles = (int64_t)n_tiles * m_tiles;
+        if (ws && M <= 256 && tiles < 512) {
+            splits = (int)((768 + tiles - 1) / tiles);
+            if (splits > 8) splits = 8;
+            if (splits > kt_all / 8) splits = kt_all / 8 > 0 ? kt_all / 8 : 1;  // >= 8 K tiles per split
+            if (forced_split > 0) splits = forced_split;
+            while (splits > 1 && (size_t)splits * M * N * sizeof(float) > ws_bytes) --splits;
+        }
+        int kt_per = (kt_all + splits - 1) / splits;
+        splits = (kt_all + kt_per - 1) / kt_per;  // no empty split
+        if (splits > 1) stages = 2;
+        g2.y = splits;
 #define DMA_LAUNCH(WQ, O32, ST)                                                                                     \
     hipLaunchKernelGGL((gemm_dma_kernel<WQ, O32, ST>), g2, block, 0, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles, \
-                       map_mode)
+                       map_mode, kt_per, ws)
 #define DMA_STAGES(WQ, O32)                                                                                         \
     do { if (stages == 2) DMA_LAUNCH(WQ, O32, 2); else if (stages == 3) DMA_LAUNCH(WQ, O32, 3); else DMA_LAUNCH(WQ, O32, 4); } while (0)
         if (wq_bit == 8) { if (out_fp32) DMA_STAGES(8, true); else DMA_STAGES(8, false); }
         else { if (out_fp32) DMA_STAGES(0, true); else DMA_STAGES(0, false); }
 #undef DMA_STAGES
 #undef DMA_LAUNCH
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess || splits == 1) return e;
+        const int64_t total = M * (N / 4);
+        const unsigned rb = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
+        if (out_fp32) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(rb), dim3(256), 0, s, ws, splits, M, N, wq_bit == 8 ? scale : nullptr, y, ldy);
+        else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(rb), dim3(256), 0, s, ws, splits, M, N, wq_bit == 8 ? scale : nullptr, y, ldy);
         return hipGetLastError();
     }
 #define GEMM_CASE(WQ, O32)                                                                                          \

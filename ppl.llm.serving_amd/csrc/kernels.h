@@ -41,9 +41,9 @@ hipError_t launch_attn_prefill(hipStream_t s, const uint16_t* qkv, const KvAddr&
 
 // ---- k_gemm.hip -------------------------------------------------------------------------------
 // y[M,N] = x[M,K] . W[N,K]^T (+ per-channel / per-group scales).  wq_bit 0/8/4.  out_fp32: y is float.
-// ldy = row stride of y in elements.
+// ldy = row stride of y in elements.  ws (optional, fp32 scratch) enables split-K at small M.
 hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const uint16_t* scale, int wq_bit, int group,
-                         int64_t M, int N, int K, void* y, int64_t ldy, bool out_fp32);
+                         int64_t M, int N, int K, void* y, int64_t ldy, bool out_fp32, float* ws = nullptr, size_t ws_bytes = 0);
 
 // ---- k_sample.hip -----------------------------------------------------------------------------
 hipError_t launch_sample_greedy(hipStream_t s, const float* logits, const float* temperatures, int batch, int vocab,

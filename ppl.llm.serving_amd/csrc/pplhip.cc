@@ -82,6 +82,8 @@ struct Rank {
     float* logits = nullptr;        // [B, V]
     float* attn_ws = nullptr;
     size_t attn_ws_bytes = 0;
+    float* gemm_ws = nullptr;  // split-K partial slabs
+    size_t gemm_ws_bytes = 0;
 
     // sampler (local rank 0)
     float *d_temp = nullptr, *d_topp = nullptr, *d_rand = nullptr, *d_lp = nullptr;
@@ -391,6 +393,8 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
         }
         R.attn_ws_bytes = attn_decode_workspace_bytes(cap_B, c->H, c->D, 32);
         ALLOC(R.attn_ws, R.attn_ws_bytes);
+        R.gemm_ws_bytes = (size_t)8 * 256 * (size_t)std::max(std::max(2 * c->inter, (c->H + 2 * c->Hkv) * c->D), std::max(hd, c->vocab_local)) * sizeof(float);
+        ALLOC(R.gemm_ws, R.gemm_ws_bytes);
 
         if (r == 0) {  // sampler lives on local rank 0 (src/backends/cuda/resource_manager.cc:315-327)
             ALLOC(R.d_temp, cap_B * 4); ALLOC(R.d_topp, cap_B * 4); ALLOC(R.d_rand, cap_B * 4);
@@ -679,7 +683,7 @@ int pplhip_run(pplhip_ctx* c, int rank, int cache_prefill) {
         Layer& L = R.layers[l];
         HIPCK(c, rank, launch_rmsnorm(s, R.h, pending, L.attn_norm, d.norm_eps, T, hd, nullptr, R.xn, pending ? R.h : nullptr));
         prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-        HIPCK(c, rank, launch_linear(s, R.xn, L.wqkv.w, L.wqkv.scale, L.wqkv.qbit, L.wqkv.group, T, L.wqkv.N, L.wqkv.K, R.qkv, L.wqkv.N, false));
+        HIPCK(c, rank, launch_linear(s, R.xn, L.wqkv.w, L.wqkv.scale, L.wqkv.qbit, L.wqkv.group, T, L.wqkv.N, L.wqkv.K, R.qkv, L.wqkv.N, false, R.gemm_ws, R.gemm_ws_bytes));
         prof_end(R, &ev);
         const KvAddr kv = make_kv_addr(d, Hkv, D, R.kv_tokens, R.kv_cache, R.kv_scale, l);
         HIPCK(c, rank, launch_rope_kv_write(s, R.qkv, R.rope, kv, d.cache_quant_bit, d.cache_quant_group, R.d_seq, R.d_sp,
@@ -688,16 +692,16 @@ int pplhip_run(pplhip_ctx* c, int rank, int cache_prefill) {
                                     nb_decode, R.max_seq_len, R.max_kv_len, H, Hkv, D, split, threads, R.attn_ws, R.att, &R);
         if (rc) return rc;
         prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-        HIPCK(c, rank, launch_linear(s, R.att, L.wo.w, L.wo.scale, L.wo.qbit, L.wo.group, T, L.wo.N, L.wo.K, R.part, hd, false));
+        HIPCK(c, rank, launch_linear(s, R.att, L.wo.w, L.wo.scale, L.wo.qbit, L.wo.group, T, L.wo.N, L.wo.K, R.part, hd, false, R.gemm_ws, R.gemm_ws_bytes));
         prof_end(R, &ev);
         if (c->tp > 1) NCCLCK(c, rank, ncclAllReduce(R.part, R.part, (size_t)T * hd, ncclFloat16, ncclSum, R.comm, s));
         HIPCK(c, rank, launch_rmsnorm(s, R.h, R.part, L.ffn_norm, d.norm_eps, T, hd, nullptr, R.xn, R.h));
         prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-        HIPCK(c, rank, launch_linear(s, R.xn, L.w13.w, L.w13.scale, L.w13.qbit, L.w13.group, T, L.w13.N, L.w13.K, R.gu, L.w13.N, false));
+        HIPCK(c, rank, launch_linear(s, R.xn, L.w13.w, L.w13.scale, L.w13.qbit, L.w13.group, T, L.w13.N, L.w13.K, R.gu, L.w13.N, false, R.gemm_ws, R.gemm_ws_bytes));
         prof_end(R, &ev);
         HIPCK(c, rank, launch_silu_mul(s, R.gu, T, inter, R.act));
         prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-        HIPCK(c, rank, launch_linear(s, R.act, L.w2.w, L.w2.scale, L.w2.qbit, L.w2.group, T, L.w2.N, L.w2.K, R.part2, hd, false));
+        HIPCK(c, rank, launch_linear(s, R.act, L.w2.w, L.w2.scale, L.w2.qbit, L.w2.group, T, L.w2.N, L.w2.K, R.part2, hd, false, R.gemm_ws, R.gemm_ws_bytes));
         prof_end(R, &ev);
         if (c->tp > 1) NCCLCK(c, rank, ncclAllReduce(R.part2, R.part2, (size_t)T * hd, ncclFloat16, ncclSum, R.comm, s));
         pending = R.part2;
@@ -711,11 +715,11 @@ int pplhip_run(pplhip_ctx* c, int rank, int cache_prefill) {
     }
     prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
     if (c->tp == 1) {
-        HIPCK(c, rank, launch_linear(s, R.hn, R.output.w, nullptr, 0, 0, B, R.output.N, hd, R.logits, d.vocab_size, true));
+        HIPCK(c, rank, launch_linear(s, R.hn, R.output.w, nullptr, 0, 0, B, R.output.N, hd, R.logits, d.vocab_size, true, R.gemm_ws, R.gemm_ws_bytes));
         prof_end(R, &ev);
     } else {
         const int vl = c->vocab_local;
-        HIPCK(c, rank, launch_linear(s, R.hn, R.output.w, nullptr, 0, 0, B, vl, hd, R.logits_local, vl, true));
+        HIPCK(c, rank, launch_linear(s, R.hn, R.output.w, nullptr, 0, 0, B, vl, hd, R.logits_local, vl, true, R.gemm_ws, R.gemm_ws_bytes));
         prof_end(R, &ev);
         NCCLCK(c, rank, ncclAllGather(R.logits_local, R.logits_gather, (size_t)B * vl, ncclFloat32, R.comm, s));
         for (int r = 0; r < c->tp; ++r)
@@ -864,8 +868,14 @@ int pplhip_op_rmsnorm(void* stream, const void* x, const void* skip, const void*
 
 int pplhip_op_linear(void* stream, const void* x, const void* w, const void* scale, int32_t wq_bit, int32_t group, int64_t M,
                      int32_t N, int32_t K, void* y, int32_t out_fp32) {
+    // split-K scratch of the stand-alone operator (the runtime owns its own per rank); one per device, never freed
+    static float* ws[16] = {nullptr};
+    static const size_t ws_bytes = (size_t)64 << 20;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return PPLHIP_DEVICE_RUNTIME_ERROR;
+    if (!ws[dev] && hipMalloc((void**)&ws[dev], ws_bytes) != hipSuccess) ws[dev] = nullptr;
     return op_rc(launch_linear((hipStream_t)stream, (const uint16_t*)x, w, (const uint16_t*)scale, wq_bit, group, M, N, K, y, N,
-                               out_fp32 != 0));
+                               out_fp32 != 0, ws[dev], ws[dev] ? ws_bytes : 0));
 }
 
 int pplhip_op_silu_mul(void* stream, const void* gate_up, int64_t T, int32_t inter, void* out) {
