@@ -737,8 +737,9 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         int splits = 1;
         static const int forced_split = getenv("PPLHIP_GEMM_SPLITK") ? atoi(getenv("PPLHIP_GEMM_SPLITK")) : 0;
         const int64_t tiles = (int64_t)n_tiles * m_tiles;
-        if (ws && M <= 256 && tiles < 512) {
-            splits = (int)((768 + tiles - 1) / tiles);
+        // (also at larger M when a tensor-parallel slice leaves fewer output tiles than CUs)
+        if (ws && ((M <= 256 && tiles < 512) || tiles < 200)) {
+            splits = M <= 256 ? (int)((768 + tiles - 1) / tiles) : (int)((384 + tiles - 1) / tiles);
             if (splits > 8) splits = 8;
             if (splits > kt_all / 8) splits = kt_all / 8 > 0 ? kt_all / 8 : 1;  // >= 8 K tiles per split
             if (forced_split > 0) splits = forced_split;

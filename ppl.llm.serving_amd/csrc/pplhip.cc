@@ -394,6 +394,7 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
         R.attn_ws_bytes = attn_decode_workspace_bytes(cap_B, c->H, c->D, 32);
         ALLOC(R.attn_ws, R.attn_ws_bytes);
         R.gemm_ws_bytes = (size_t)8 * 256 * (size_t)std::max(std::max(2 * c->inter, (c->H + 2 * c->Hkv) * c->D), std::max(hd, c->vocab_local)) * sizeof(float);
+        R.gemm_ws_bytes = std::max<size_t>(R.gemm_ws_bytes, (size_t)96 << 20);
         ALLOC(R.gemm_ws, R.gemm_ws_bytes);
 
         if (r == 0) {  // sampler lives on local rank 0 (src/backends/cuda/resource_manager.cc:315-327)
