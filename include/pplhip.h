@@ -262,6 +262,10 @@ PPLHIP_API int pplhip_op_rmsnorm(void* stream, const void* x, const void* skip, 
 PPLHIP_API int pplhip_op_linear(void* stream, const void* x, const void* w, const void* scale, int32_t wq_bit,
                                 int32_t group, int64_t M, int32_t N, int32_t K, void* y, int32_t out_fp32);
 
+/* fused K3 + K10: W rows interleaved (gate_0, up_0, gate_1, up_1, ...), N = 2 * inter; y[M, N/2] = silu(gate) * up. */
+PPLHIP_API int pplhip_op_linear_swiglu(void* stream, const void* x, const void* w, const void* scale, int32_t wq_bit,
+                                       int32_t group, int64_t M, int32_t N, int32_t K, void* y);
+
 PPLHIP_API int pplhip_op_silu_mul(void* stream, const void* gate_up, int64_t T, int32_t inter, void* out);
 
 /* description of a KV slab for the attention / cache-write operators */

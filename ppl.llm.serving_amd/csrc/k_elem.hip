@@ -110,4 +110,31 @@ hipError_t launch_silu_mul(hipStream_t s, const uint16_t* gate_up, int64_t T, in
     return hipGetLastError();
 }
 
+// Row interleave used for the fused SwiGLU GEMM: dst row r = src row (r even ? r/2 : rows/2 + r/2), i.e. the
+// container's [gate rows | up rows] order becomes (gate_0, up_0, gate_1, up_1, ...) on the device.
+template <typename U>
+__global__ __launch_bounds__(256) void interleave_rows_kernel(const U* __restrict__ src, U* __restrict__ dst, int rows,
+                                                              int64_t units_per_row) {
+    const int64_t total = (int64_t)rows * units_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / units_per_row, c = i - r * units_per_row;
+        const int64_t sr = (r & 1) ? (rows / 2 + (r >> 1)) : (r >> 1);
+        dst[i] = src[sr * units_per_row + c];
+    }
+}
+
+hipError_t launch_interleave_rows(hipStream_t s, const void* src, void* dst, int rows, int64_t row_bytes) {
+    if (rows == 0 || row_bytes == 0) return hipSuccess;
+    if ((rows & 1) || (row_bytes & 1)) return hipErrorInvalidValue;
+    const bool wide = (row_bytes % 16) == 0;
+    const int64_t units = wide ? row_bytes / 16 : row_bytes / 2;
+    int64_t blocks = ((int64_t)rows * units + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (wide)
+        hipLaunchKernelGGL(interleave_rows_kernel<uint4>, dim3((unsigned)blocks), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, rows, units);
+    else
+        hipLaunchKernelGGL(interleave_rows_kernel<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst, rows, units);
+    return hipGetLastError();
+}
+
 }  // namespace pplhip

@@ -26,7 +26,26 @@ constexpr int G_BN = 128, G_BM = 128, G_BK = 64;
 
 __device__ __forceinline__ int g_swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-template <int WQ, bool OUT32>
+// Epilogues: EPI 0 = fp16 output, 1 = fp32 output (logits), 2 = fused SwiGLU -- the weight rows are stored interleaved
+// (gate_0, up_0, gate_1, up_1, ...), so the 4 consecutive output channels a lane owns are two (gate, up) pairs and the
+// lane writes silu(gate) * up for both: y is then [M, N/2] (K10 fused into the producing GEMM; numerics as the separate
+// kernel: gate and up are rounded to fp16 first).
+enum { EPI_F16 = 0, EPI_F32 = 1, EPI_SWIGLU = 2 };
+template <int EPI>
+__device__ __forceinline__ void store4(void* yv, int64_t ldy, int64_t m, int n, float v0, float v1, float v2, float v3) {
+    if constexpr (EPI == EPI_F32) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(yv) + m * ldy + n) = make_float4(v0, v1, v2, v3);
+    } else if constexpr (EPI == EPI_F16) {
+        const h4 o = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(yv) + m * ldy + n) = __builtin_bit_cast(uint2, o);
+    } else {
+        const float g0 = round_h(v0), u0 = round_h(v1), g1 = round_h(v2), u1 = round_h(v3);
+        const h2 o = {(_Float16)(g0 / (1.0f + __expf(-g0)) * u0), (_Float16)(g1 / (1.0f + __expf(-g1)) * u1)};
+        *reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(yv) + m * ldy + (n >> 1)) = __builtin_bit_cast(uint32_t, o);
+    }
+}
+
+template <int WQ, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(const uint16_t* __restrict__ x, const void* __restrict__ wv,
                                                    const uint16_t* __restrict__ scale, int64_t M, int N, int K, int group,
                                                    void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles) {
@@ -183,15 +202,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const uint16_t* __restrict__ 
         for (int j = 0; j < 4; ++j) {
             const int64_t m = m0 + wm * 64 + j * 16 + l15;
             if (m >= M) continue;
-            if constexpr (OUT32) {
-                float4 o = make_float4(acc[i][j][0] * sc[0], acc[i][j][1] * sc[1], acc[i][j][2] * sc[2], acc[i][j][3] * sc[3]);
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(yv) + m * ldy + n) = o;
-            } else {
-                h4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (_Float16)(acc[i][j][r] * sc[r]);
-                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(yv) + m * ldy + n) = __builtin_bit_cast(uint2, o);
-            }
+            store4<EPI>(yv, ldy, m, n, acc[i][j][0] * sc[0], acc[i][j][1] * sc[1], acc[i][j][2] * sc[2], acc[i][j][3] * sc[3]);
         }
     }
 }
@@ -233,7 +244,7 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
 
-template <int WQ, bool OUT32, int G_ST>  // WQ = 8: int8 weights + per-channel scale; WQ = 0: fp16 weights
+template <int WQ, int EPI, int G_ST>  // WQ = 8: int8 weights + per-channel scale; WQ = 0: fp16 weights
 __global__ __launch_bounds__(256) void gemm_dma_kernel(const uint16_t* __restrict__ x, const void* __restrict__ wv,
                                                              const uint16_t* __restrict__ scale, int64_t M, int N, int K,
                                                              void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles,
@@ -401,16 +412,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const uint16_t* __restric
         for (int j = 0; j < 4; ++j) {
             const int64_t m = m0 + wm * 64 + j * 16 + l15;
             if (m >= M) continue;
-            if constexpr (OUT32) {
-                float4 o = make_float4(acc[i][j][0] * (float)sh[0], acc[i][j][1] * (float)sh[1], acc[i][j][2] * (float)sh[2],
-                                       acc[i][j][3] * (float)sh[3]);
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(yv) + m * ldy + n) = o;
-            } else {
-                h4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (_Float16)(acc[i][j][r] * (float)sh[r]);
-                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(yv) + m * ldy + n) = __builtin_bit_cast(uint2, o);
-            }
+            store4<EPI>(yv, ldy, m, n, acc[i][j][0] * (float)sh[0], acc[i][j][1] * (float)sh[1], acc[i][j][2] * (float)sh[2],
+                        acc[i][j][3] * (float)sh[3]);
         }
     }
 }
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const uint16_t* __restric
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int H_BN = 256, H_BM = 256, H_ST = 3;
 
-template <bool OUT32>
+template <int EPI>
 __global__ __launch_bounds__(512) void gemm_w8_dma256_kernel(const uint16_t* __restrict__ x, const int8_t* __restrict__ w,
                                                              const uint16_t* __restrict__ scale, int64_t M, int N, int K,
                                                              void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles) {
@@ -533,21 +536,13 @@ __global__ __launch_bounds__(512) void gemm_w8_dma256_kernel(const uint16_t* __r
         for (int j = 0; j < 8; ++j) {
             const int64_t m = m0 + wm * 128 + j * 16 + l15;
             if (m >= M) continue;
-            if constexpr (OUT32) {
-                float4 o = make_float4(acc[i][j][0] * (float)sh[0], acc[i][j][1] * (float)sh[1], acc[i][j][2] * (float)sh[2],
-                                       acc[i][j][3] * (float)sh[3]);
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(yv) + m * ldy + n) = o;
-            } else {
-                h4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (_Float16)(acc[i][j][r] * (float)sh[r]);
-                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(yv) + m * ldy + n) = __builtin_bit_cast(uint2, o);
-            }
+            store4<EPI>(yv, ldy, m, n, acc[i][j][0] * (float)sh[0], acc[i][j][1] * (float)sh[1], acc[i][j][2] * (float)sh[2],
+                        acc[i][j][3] * (float)sh[3]);
         }
     }
 }
 
-template <int WQ, int MT, bool OUT32, int NW>
+template <int WQ, int MT, int EPI, int NW>
 __global__ __launch_bounds__(NW * 64) void gemv_kernel(const uint16_t* __restrict__ x, const void* __restrict__ wv,
                                                    const uint16_t* __restrict__ scale, int64_t M, int N, int K, int group,
                                                    void* __restrict__ yv, int64_t ldy) {
@@ -575,7 +570,6 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const uint16_t* __restric
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 4
     for (int st = s_begin; st < s_end; ++st) {
         const int k = st * KSTEP + kq * KL;
         const bool ok = k < K;  // K is a multiple of KL (checked by the launcher)
@@ -627,21 +621,13 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const uint16_t* __restric
                 }
                 const int64_t m = mt * 16 + l15;
                 if (m >= M) continue;
-                if constexpr (OUT32) {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(yv) + m * ldy + nn) =
-                        make_float4(v[0] * sc[0], v[1] * sc[1], v[2] * sc[2], v[3] * sc[3]);
-                } else {
-                    h4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (_Float16)(v[r] * sc[r]);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(yv) + m * ldy + nn) = __builtin_bit_cast(uint2, o);
-                }
+                store4<EPI>(yv, ldy, m, nn, v[0] * sc[0], v[1] * sc[1], v[2] * sc[2], v[3] * sc[3]);
             }
         }
     }
 }
 
-template <int WQ, bool OUT32>
+template <int WQ, int EPI>
 static hipError_t launch_gemv(hipStream_t s, const uint16_t* x, const void* w, const uint16_t* scale, int group, int64_t M,
                               int N, int K, void* y, int64_t ldy) {
     dim3 grid((unsigned)((N + 15) / 16));
@@ -651,8 +637,8 @@ static hipError_t launch_gemv(hipStream_t s, const uint16_t* x, const void* w, c
     const int nw = forced_nw ? forced_nw : ((N + 15) / 16 <= 1024 ? 8 : 4);
 #define GEMV_CASE(MT)                                                                                                    \
     if (mt == MT) {                                                                                                      \
-        if (nw == 8) hipLaunchKernelGGL((gemv_kernel<WQ, MT, OUT32, 8>), grid, dim3(512), 0, s, x, w, scale, M, N, K, group, y, ldy); \
-        else hipLaunchKernelGGL((gemv_kernel<WQ, MT, OUT32, 4>), grid, dim3(256), 0, s, x, w, scale, M, N, K, group, y, ldy);       \
+        if (nw == 8) hipLaunchKernelGGL((gemv_kernel<WQ, MT, EPI, 8>), grid, dim3(512), 0, s, x, w, scale, M, N, K, group, y, ldy); \
+        else hipLaunchKernelGGL((gemv_kernel<WQ, MT, EPI, 4>), grid, dim3(256), 0, s, x, w, scale, M, N, K, group, y, ldy);       \
         return hipGetLastError();                                                                                        \
     }
     GEMV_CASE(1) GEMV_CASE(2)
@@ -661,7 +647,7 @@ static hipError_t launch_gemv(hipStream_t s, const uint16_t* x, const void* w, c
 }
 
 // split-K reduce: y[m][n] = (sum_z slab[z][m][n]) * scale[n]  (scale == NULL: 1)
-template <bool OUT32>
+template <int EPI>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int64_t M, int N,
                                                             const uint16_t* __restrict__ scale, void* __restrict__ yv, int64_t ldy) {
     const int64_t total = M * (N / 4);
@@ -677,18 +663,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             const h4 sh = __builtin_bit_cast(h4, *reinterpret_cast<const uint2*>(scale + n));
             v.x *= (float)sh[0]; v.y *= (float)sh[1]; v.z *= (float)sh[2]; v.w *= (float)sh[3];
         }
-        if constexpr (OUT32) {
-            *reinterpret_cast<float4*>(reinterpret_cast<float*>(yv) + m * ldy + n) = v;
-        } else {
-            const h4 o = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(yv) + m * ldy + n) = __builtin_bit_cast(uint2, o);
-        }
+        store4<EPI>(yv, ldy, m, n, v.x, v.y, v.z, v.w);
     }
 }
 
 hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const uint16_t* scale, int wq_bit, int group,
-                         int64_t M, int N, int K, void* y, int64_t ldy, bool out_fp32, float* ws, size_t ws_bytes) {
+                         int64_t M, int N, int K, void* y, int64_t ldy, bool out_fp32, float* ws, size_t ws_bytes, bool swiglu) {
     if (M == 0) return hipSuccess;
+    if (swiglu && out_fp32) return hipErrorInvalidValue;
+    const int epi = swiglu ? EPI_SWIGLU : (out_fp32 ? EPI_F32 : EPI_F16);
     if (N % 4 || ldy % 4) return hipErrorInvalidValue;
     if (wq_bit == 0 && K % 8) return hipErrorInvalidValue;
     if (wq_bit == 8 && K % 16) return hipErrorInvalidValue;
@@ -696,8 +679,9 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
     if (M <= 16 && !getenv("PPLHIP_GEMM_NOSKINNY")) {  // above 16 rows the split-K tiled kernel is faster (profiles/gemm_microbench.py)
 #define GEMV_DISPATCH(WQ)                                                                                      \
     if (wq_bit == WQ)                                                                                          \
-        return out_fp32 ? launch_gemv<WQ, true>(s, x, w, scale, group, M, N, K, y, ldy)                        \
-                        : launch_gemv<WQ, false>(s, x, w, scale, group, M, N, K, y, ldy);
+        return epi == EPI_F32 ? launch_gemv<WQ, EPI_F32>(s, x, w, scale, group, M, N, K, y, ldy)               \
+             : epi == EPI_F16 ? launch_gemv<WQ, EPI_F16>(s, x, w, scale, group, M, N, K, y, ldy)               \
+                              : launch_gemv<WQ, EPI_SWIGLU>(s, x, w, scale, group, M, N, K, y, ldy);
         GEMV_DISPATCH(0) GEMV_DISPATCH(8) GEMV_DISPATCH(4)
 #undef GEMV_DISPATCH
     }
@@ -712,14 +696,14 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         dim3 g256((unsigned)((nt2 + 7) / 8 * 8 * mt2));
         static bool attr_set = false;
         if (!attr_set) {
-            hipFuncSetAttribute((const void*)gemm_w8_dma256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipFuncSetAttribute((const void*)gemm_w8_dma256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gemm_w8_dma256_kernel<EPI_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gemm_w8_dma256_kernel<EPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gemm_w8_dma256_kernel<EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }
-        if (out_fp32)
-            hipLaunchKernelGGL((gemm_w8_dma256_kernel<true>), g256, dim3(512), lds, s, x, (const int8_t*)w, scale, M, N, K, y, ldy, nt2, mt2);
-        else
-            hipLaunchKernelGGL((gemm_w8_dma256_kernel<false>), g256, dim3(512), lds, s, x, (const int8_t*)w, scale, M, N, K, y, ldy, nt2, mt2);
+#define L256(E) hipLaunchKernelGGL((gemm_w8_dma256_kernel<E>), g256, dim3(512), lds, s, x, (const int8_t*)w, scale, M, N, K, y, ldy, nt2, mt2)
+        if (epi == EPI_F32) L256(EPI_F32); else if (epi == EPI_F16) L256(EPI_F16); else L256(EPI_SWIGLU);
+#undef L256
         return hipGetLastError();
     }
     if ((wq_bit == 8 || wq_bit == 0) && K % G_BK == 0 && !getenv("PPLHIP_GEMM_GENERIC")) {
@@ -754,25 +738,28 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
                        map_mode, kt_per, ws)
 #define DMA_STAGES(WQ, O32)                                                                                         \
     do { if (stages == 2) DMA_LAUNCH(WQ, O32, 2); else if (stages == 3) DMA_LAUNCH(WQ, O32, 3); else DMA_LAUNCH(WQ, O32, 4); } while (0)
-        if (wq_bit == 8) { if (out_fp32) DMA_STAGES(8, true); else DMA_STAGES(8, false); }
-        else { if (out_fp32) DMA_STAGES(0, true); else DMA_STAGES(0, false); }
+#define DMA_EPI(WQ) do { if (epi == EPI_F32) DMA_STAGES(WQ, EPI_F32); else if (epi == EPI_F16) DMA_STAGES(WQ, EPI_F16); else DMA_STAGES(WQ, EPI_SWIGLU); } while (0)
+        if (wq_bit == 8) DMA_EPI(8); else DMA_EPI(0);
+#undef DMA_EPI
 #undef DMA_STAGES
 #undef DMA_LAUNCH
         hipError_t e = hipGetLastError();
         if (e != hipSuccess || splits == 1) return e;
         const int64_t total = M * (N / 4);
         const unsigned rb = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
-        if (out_fp32) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(rb), dim3(256), 0, s, ws, splits, M, N, wq_bit == 8 ? scale : nullptr, y, ldy);
-        else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(rb), dim3(256), 0, s, ws, splits, M, N, wq_bit == 8 ? scale : nullptr, y, ldy);
+#define RED(E) hipLaunchKernelGGL(splitk_reduce_kernel<E>, dim3(rb), dim3(256), 0, s, ws, splits, M, N, wq_bit == 8 ? scale : nullptr, y, ldy)
+        if (epi == EPI_F32) RED(EPI_F32); else if (epi == EPI_F16) RED(EPI_F16); else RED(EPI_SWIGLU);
+#undef RED
         return hipGetLastError();
     }
 #define GEMM_CASE(WQ, O32)                                                                                          \
-    if (wq_bit == WQ && out_fp32 == O32) {                                                                          \
+    if (wq_bit == WQ && epi == (int)O32) {                                                                          \
         hipLaunchKernelGGL((gemm_kernel<WQ, O32>), grid, block, 0, s, x, w, scale, M, N, K, group, y, ldy, n_tiles, \
                            m_tiles);                                                                                \
         return hipGetLastError();                                                                                   \
     }
-    GEMM_CASE(0, false) GEMM_CASE(0, true) GEMM_CASE(8, false) GEMM_CASE(8, true) GEMM_CASE(4, false) GEMM_CASE(4, true)
+    GEMM_CASE(0, EPI_F16) GEMM_CASE(0, EPI_F32) GEMM_CASE(0, EPI_SWIGLU) GEMM_CASE(8, EPI_F16) GEMM_CASE(8, EPI_F32) GEMM_CASE(8, EPI_SWIGLU)
+    GEMM_CASE(4, EPI_F16) GEMM_CASE(4, EPI_F32) GEMM_CASE(4, EPI_SWIGLU)
 #undef GEMM_CASE
     return hipErrorInvalidValue;
 }

@@ -42,8 +42,12 @@ hipError_t launch_attn_prefill(hipStream_t s, const uint16_t* qkv, const KvAddr&
 // ---- k_gemm.hip -------------------------------------------------------------------------------
 // y[M,N] = x[M,K] . W[N,K]^T (+ per-channel / per-group scales).  wq_bit 0/8/4.  out_fp32: y is float.
 // ldy = row stride of y in elements.  ws (optional, fp32 scratch) enables split-K at small M.
+// swiglu: the weight rows are interleaved (gate_i, up_i) and y[M, N/2] = silu(gate) * up (fused K10).
 hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const uint16_t* scale, int wq_bit, int group,
-                         int64_t M, int N, int K, void* y, int64_t ldy, bool out_fp32, float* ws = nullptr, size_t ws_bytes = 0);
+                         int64_t M, int N, int K, void* y, int64_t ldy, bool out_fp32, float* ws = nullptr, size_t ws_bytes = 0,
+                         bool swiglu = false);
+// dst row r = src row perm(r): r even -> r/2 (gate), r odd -> half + r/2 (up).  row_bytes % 4 == 0.
+hipError_t launch_interleave_rows(hipStream_t s, const void* src, void* dst, int rows, int64_t row_bytes);
 
 // ---- k_sample.hip -----------------------------------------------------------------------------
 hipError_t launch_sample_greedy(hipStream_t s, const float* logits, const float* temperatures, int batch, int vocab,

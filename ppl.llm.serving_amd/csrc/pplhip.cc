@@ -383,7 +383,6 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
         ALLOC(R.att, (uint64_t)cap_T * c->H * c->D * 2);
         ALLOC(R.part, (uint64_t)cap_T * hd * 2);
         ALLOC(R.part2, (uint64_t)cap_T * hd * 2);
-        ALLOC(R.gu, (uint64_t)cap_T * 2 * c->inter * 2);
         ALLOC(R.act, (uint64_t)cap_T * c->inter * 2);
         ALLOC(R.hn, (uint64_t)cap_B * hd * 2);
         ALLOC(R.logits, (uint64_t)cap_B * d.vocab_size * 4);
@@ -424,6 +423,20 @@ int pplhip_rank_set_tensor(pplhip_ctx* c, int rank, const char* name, const void
     if (!find_tensor(c, R, name, &p, &b)) return fail(c, rank, PPLHIP_NOT_FOUND, std::string("unknown tensor ") + name);
     if (b != bytes) return fail(c, rank, PPLHIP_INVALID_VALUE, std::string("tensor ") + name + ": got " + std::to_string(bytes) + " bytes, want " + std::to_string(b));
     HIPCK(c, rank, hipSetDevice(R.device));
+    const char* w13 = strstr(name, "feed_forward.w13.");
+    if (w13) {
+        // the container stores w13 as [gate rows | up rows]; on the device the rows are interleaved (gate_i, up_i) so
+        // that the GEMM epilogue can apply SwiGLU (kernels.h: launch_linear swiglu)
+        void* tmp = nullptr;
+        HIPCK(c, rank, hipMalloc(&tmp, bytes));
+        hipError_t e = hipMemcpy(tmp, data, bytes, hipMemcpyHostToDevice);
+        const int rows = 2 * c->inter;
+        if (e == hipSuccess) e = launch_interleave_rows(R.stream, tmp, p, rows, (int64_t)(bytes / rows));
+        if (e == hipSuccess) e = hipStreamSynchronize(R.stream);
+        hipFree(tmp);
+        if (e != hipSuccess) return fail(c, rank, PPLHIP_DEVICE_RUNTIME_ERROR, std::string("interleave w13: ") + hipGetErrorString(e));
+        return 0;
+    }
     HIPCK(c, rank, hipMemcpy(p, data, bytes, hipMemcpyHostToDevice));
     return 0;
 }
@@ -487,7 +500,17 @@ int pplhip_rank_init_synthetic(pplhip_ctx* c, int rank, uint64_t seed) {
         HIPCK(c, rank, launch_synth_fill(s, 4, seed, tid(l, 6), 0, 0.f, hd, L.ffn_norm));
         HIPCK(c, rank, lin(L.wqkv, l, 2));
         HIPCK(c, rank, lin(L.wo, l, 4));
-        HIPCK(c, rank, lin(L.w13, l, 7));
+        {   // generated in container order, then row-interleaved like an uploaded tensor
+            Linear tmp = L.w13;
+            HIPCK(c, rank, hipMalloc(&tmp.w, L.w13.w_bytes()));
+            if (L.w13.s_bytes()) HIPCK(c, rank, hipMalloc((void**)&tmp.scale, L.w13.s_bytes()));
+            HIPCK(c, rank, lin(tmp, l, 7));
+            HIPCK(c, rank, launch_interleave_rows(s, tmp.w, L.w13.w, L.w13.N, (int64_t)(L.w13.w_bytes() / L.w13.N)));
+            if (L.w13.s_bytes()) HIPCK(c, rank, launch_interleave_rows(s, tmp.scale, L.w13.scale, L.w13.N, (int64_t)(L.w13.s_bytes() / L.w13.N)));
+            HIPCK(c, rank, hipStreamSynchronize(s));
+            hipFree(tmp.w);
+            if (tmp.scale) hipFree(tmp.scale);
+        }
         HIPCK(c, rank, lin(L.w2, l, 9));
     }
     HIPCK(c, rank, hipStreamSynchronize(s));
@@ -698,9 +721,9 @@ int pplhip_run(pplhip_ctx* c, int rank, int cache_prefill) {
         if (c->tp > 1) NCCLCK(c, rank, ncclAllReduce(R.part, R.part, (size_t)T * hd, ncclFloat16, ncclSum, R.comm, s));
         HIPCK(c, rank, launch_rmsnorm(s, R.h, R.part, L.ffn_norm, d.norm_eps, T, hd, nullptr, R.xn, R.h));
         prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-        HIPCK(c, rank, launch_linear(s, R.xn, L.w13.w, L.w13.scale, L.w13.qbit, L.w13.group, T, L.w13.N, L.w13.K, R.gu, L.w13.N, false, R.gemm_ws, R.gemm_ws_bytes));
+        HIPCK(c, rank, launch_linear(s, R.xn, L.w13.w, L.w13.scale, L.w13.qbit, L.w13.group, T, L.w13.N, L.w13.K, R.act, inter, false,
+                                     R.gemm_ws, R.gemm_ws_bytes, /*swiglu=*/true));  // K3 + K10 fused
         prof_end(R, &ev);
-        HIPCK(c, rank, launch_silu_mul(s, R.gu, T, inter, R.act));
         prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
         HIPCK(c, rank, launch_linear(s, R.act, L.w2.w, L.w2.scale, L.w2.qbit, L.w2.group, T, L.w2.N, L.w2.K, R.part2, hd, false, R.gemm_ws, R.gemm_ws_bytes));
         prof_end(R, &ev);
@@ -877,6 +900,12 @@ int pplhip_op_linear(void* stream, const void* x, const void* w, const void* sca
     if (!ws[dev] && hipMalloc((void**)&ws[dev], ws_bytes) != hipSuccess) ws[dev] = nullptr;
     return op_rc(launch_linear((hipStream_t)stream, (const uint16_t*)x, w, (const uint16_t*)scale, wq_bit, group, M, N, K, y, N,
                                out_fp32 != 0, ws[dev], ws[dev] ? ws_bytes : 0));
+}
+
+int pplhip_op_linear_swiglu(void* stream, const void* x, const void* w, const void* scale, int32_t wq_bit, int32_t group, int64_t M,
+                            int32_t N, int32_t K, void* y) {
+    return op_rc(launch_linear((hipStream_t)stream, (const uint16_t*)x, w, (const uint16_t*)scale, wq_bit, group, M, N, K, y, N / 2,
+                               false, nullptr, 0, true));
 }
 
 int pplhip_op_silu_mul(void* stream, const void* gate_up, int64_t T, int32_t inter, void* out) {

@@ -331,3 +331,38 @@ def test_sampler_greedy_and_topk():
         lse = np.log(np.exp(x - x.max()).sum()) + x.max()
         assert abs(lp2[b] - (x[tok2[b]] - lse)) < 1e-3
     ctx.close()
+
+
+@pytest.mark.parametrize("wq", [0, 8, 4])
+@pytest.mark.parametrize("M,inter,K", [(3, 64, 128), (40, 192, 256), (300, 1376, 512)])
+def test_linear_swiglu_fused(wq, M, inter, K):
+    """K3 + K10 fused: the GEMM over row-interleaved (gate_i, up_i) weights writes silu(gate) * up directly."""
+    m = load_pplhip()
+    group = 128
+    rng = np.random.RandomState(M + inter + wq)
+    N = 2 * inter
+    x = f16(rng.randn(M, K) * 0.5)
+    if wq == 0:
+        w, scale = f16(rng.randn(N, K) * 0.08), None
+    elif wq == 8:
+        w, scale = rng.randint(-127, 128, size=(N, K)).astype(np.int8), f16(0.0008 * (0.5 + rng.rand(N)))
+    else:
+        w, scale = rng.randint(0, 256, size=(N, K // 2)).astype(np.uint8), f16(0.015 * (0.5 + rng.rand(N, K // group)))
+    gu = np.empty((M, N), dtype=np.float32)
+    xs = x.astype(np.float32)
+    ref.lib().ref_linear_raw(xs.ctypes.data, w.ctypes.data, None if scale is None else scale.ctypes.data, wq, group, M, N, K,
+                             gu.ctypes.data, 0)
+    want = np.empty((M, inter), dtype=np.float32)
+    ref.lib().ref_silu_mul(gu.ctypes.data, M, inter, want.ctypes.data)
+    perm = np.empty(N, dtype=np.int64)
+    perm[0::2], perm[1::2] = np.arange(inter), inter + np.arange(inter)
+    wi = np.ascontiguousarray(w[perm])
+    si = None if scale is None else np.ascontiguousarray(scale[perm])
+    y = torch.empty((M, inter), dtype=torch.float16, device="cuda")
+    dx, dw = dev(x), dev(wi)
+    ds = dev(si) if si is not None else None
+    ck(m.lib().pplhip_op_linear_swiglu(None, dx.data_ptr(), dw.data_ptr(), ds.data_ptr() if ds is not None else None, wq, group,
+                                       M, N, K, y.data_ptr()))
+    mag = np.abs(want).max()
+    rel = 6e-3 if wq == 4 else 3e-3   # two fp16 roundings upstream of the product
+    close_f16(y.cpu().numpy(), want, rel=rel, abs_=rel * mag * (0.25 if wq == 4 else 0.05) + 1e-5)
