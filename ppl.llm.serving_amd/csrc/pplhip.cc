@@ -404,7 +404,7 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
                 ALLOC(R.count_map, (uint64_t)cap_B * d.vocab_size * 2);
                 ALLOC(R.d_slots, cap_B * 8);
                 ALLOC(R.d_rep, cap_B * 4); ALLOC(R.d_pres, cap_B * 4); ALLOC(R.d_freq, cap_B * 4); ALLOC(R.d_ptemp, cap_B * 4);
-                HIPCK(cp, r, hipMemset(R.count_map, 0, (uint64_t)cap_B * d.vocab_size * 2));
+                HIPCK(cp, r, hipMemsetAsync(R.count_map, 0, (uint64_t)cap_B * d.vocab_size * 2, R.stream));
             }
         }
 #undef ALLOC
@@ -561,8 +561,11 @@ int pplhip_kv_alloc(pplhip_ctx* c, int rank, uint64_t tokens) {
         }
     }
     // deterministic contents for never-written slots (the reference's cudaMalloc leaves them undefined)
-    HIPCK(c, rank, hipMemset(R.kv_cache, 0, tokens * kb));
-    if (sb) HIPCK(c, rank, hipMemset(R.kv_scale, 0, tokens * sb));
+    // stream-ordered on the rank's own (non-blocking) stream: a null-stream memset is NOT ordered against it and could
+    // land after the first steps have written the slab
+    HIPCK(c, rank, hipMemsetAsync(R.kv_cache, 0, tokens * kb, R.stream));
+    if (sb) HIPCK(c, rank, hipMemsetAsync(R.kv_scale, 0, tokens * sb, R.stream));
+    HIPCK(c, rank, hipStreamSynchronize(R.stream));
     R.kv_tokens = tokens;
     return 0;
 }
