@@ -4,12 +4,14 @@
 // src/engine/llm_engine.cc:114) and a 1-token request all run this one kernel.  MFMA-bound.
 //
 // Work decomposition (wave64, gfx950, mfma_f32_16x16x32_f16):
-//   grid  = (ceil(max_seq_len / 64), requests, H); block = 4 waves; wave w owns 16 query rows.
-//   per KV tile of 64 keys:  K tile -> LDS as fp16 [key][D] (16-B chunks XOR-swizzled against bank conflicts),
-//                            V tile -> LDS TRANSPOSED [d][key] (key-pair dwords, XOR-swizzled) because the PV
-//                            MFMA contracts over keys and needs them contiguous per lane.
+//   grid  = (ceil(max_seq_len / 128), requests, H); block = 8 waves; wave w owns 16 query rows.
+//   per KV tile of 128 keys:  K tile -> LDS as fp16 [key][D] (16-B chunks XOR-swizzled against bank conflicts),
+//                             V tile -> LDS TRANSPOSED [d][key] (key-pair dwords, XOR-swizzled) because the PV
+//                             MFMA contracts over keys and needs them contiguous per lane.
+//   The tile is staged global -> registers -> LDS; the loads of tile t+1 are issued BEFORE the MFMAs of tile t and
+//   converted / written after them (register prefetch, T14 of the CDNA guide), so HBM/L2 latency hides under compute.
 //   S^T = K . Q^T  (A = K fragment from LDS, B = Q fragment in registers): the C layout then gives every lane
-//   16 scores of ONE query row (col = lane&15), so the online softmax is lane-local plus two xor-shuffles and
+//   32 scores of ONE query row (col = lane&15), so the online softmax is lane-local plus two xor-shuffles and
 //   the probabilities are already in MFMA A-operand order for O += P . V (the k-slot permutation this implies
 //   is applied identically to the V^T reads).
 //   int8 KV is dequantised to fp16 while staging (one fp16 rounding of q*scale; DESIGN.md "numerics").
@@ -18,9 +20,10 @@
 
 namespace pplhip {
 
-constexpr int PF_BM = 64;   // query rows per block
-constexpr int PF_BN = 64;   // keys per tile
-constexpr int PF_VS = 34;   // dword stride of a V^T row (64 keys = 32 dwords + 2 pad)
+constexpr int PF_BM = 128;  // query rows per block
+constexpr int PF_BN = 128;  // keys per tile
+constexpr int PF_VS = 66;   // dword stride of a V^T row (128 keys = 64 dwords + 2 pad)
+constexpr int PF_THREADS = 512;
 
 template <int D>
 __device__ __forceinline__ int k_swz(int key) {
@@ -31,16 +34,19 @@ __device__ __forceinline__ int k_swz(int key) {
 __device__ __forceinline__ int v_swz(int ch) { return ((ch >> 4) & 7) << 2; }
 
 template <int QBIT, int D>
-__global__ __launch_bounds__(256) void attn_prefill_kernel(const uint16_t* __restrict__ qkv, KvAddr kv,
-                                                           const int64_t* __restrict__ seq_starts,
-                                                           const int64_t* __restrict__ start_pos,
-                                                           const int64_t* __restrict__ cache_indices, int64_t max_pages,
-                                                           int64_t b0, int H, int Hkv, uint16_t* __restrict__ out) {
+__global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t* __restrict__ qkv, KvAddr kv,
+                                                                  const int64_t* __restrict__ seq_starts,
+                                                                  const int64_t* __restrict__ start_pos,
+                                                                  const int64_t* __restrict__ cache_indices,
+                                                                  int64_t max_pages, int64_t b0, int H, int Hkv,
+                                                                  uint16_t* __restrict__ out) {
     constexpr int ELT = QBIT == 8 ? 1 : 2;
-    constexpr int CH = 16 / ELT;
-    constexpr int LPT = D / CH;
+    constexpr int CH = 16 / ELT;           // channels in one 16-byte piece
+    constexpr int LPT = D / CH;            // pieces per row
     constexpr int KSTEPS = D / 32;
     constexpr int DT = D / 16;
+    constexpr int NITEMS = (PF_BN / 2) * LPT;                                // (key pair, piece) staging items per tile
+    constexpr int IPT = (NITEMS + PF_THREADS - 1) / PF_THREADS;              // items per thread (1 or 2)
     __shared__ __attribute__((aligned(16))) uint16_t Ks[PF_BN * D];
     __shared__ __attribute__((aligned(16))) uint32_t Vt[D * PF_VS];
 
@@ -57,8 +63,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const uint16_t* __res
 
     // Q fragments: B operand, lane (n = query row l15, kq) holds Q[row][ks*32 + kq*8 .. +8]
     int64_t qi = q0 + wave * 16 + l15;
-    const bool qvalid = qi < seqlen;
-    if (!qvalid) qi = seqlen - 1;
+    if (qi >= seqlen) qi = seqlen - 1;
     const int64_t qpos = sp + qi;
     const uint16_t* qrow = qkv + (seq_starts[b] + qi) * rowstride + (int64_t)hq * D;
     h8 qf[KSTEPS];
@@ -74,132 +79,166 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const uint16_t* __res
     const int64_t last_q = (q0 + PF_BM - 1 < seqlen - 1) ? q0 + PF_BM - 1 : seqlen - 1;
     const int64_t kv_end = sp + last_q + 1;   // keys needed by this block: [0, kv_end)
     const int ntiles = (int)((kv_end + PF_BN - 1) / PF_BN);
+    // waves whose 16 rows lie entirely beyond the sequence still help staging but skip the MFMAs
+    const bool wave_active = (q0 + wave * 16) < seqlen;
 
     const char* kbase = reinterpret_cast<const char*>(kv.cache) + (int64_t)hk * kv.sH * ELT;
     const char* vbase = kbase + kv.sKV * ELT;
     const uint16_t* ksbase = kv.scale + (int64_t)hk * kv.ssH;
     const uint16_t* vsbase = ksbase + kv.ssKV;
 
+    // ---- register staging of one tile: raw 16-byte pieces of two adjacent keys (+ their int8 group scales) ---------
+    uint4 kraw[IPT][2], vraw[IPT][2];
+    uint32_t ksc[IPT][2], vsc[IPT][2];  // int8: two fp16 scales (the piece's two groups of 8 channels)
+    auto load_tile = [&](int tile) {
+        const int64_t key0 = (int64_t)tile * PF_BN;
+#pragma unroll
+        for (int it = 0; it < IPT; ++it) {
+            const int item = threadIdx.x + it * PF_THREADS;
+            if (item < NITEMS) {
+                const int c = item % LPT, kp = item / LPT;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    int64_t key = key0 + 2 * kp + e;
+                    if (key >= kv_end) key = kv_end - 1;  // masked later (beyond every row's causal horizon)
+                    const int64_t slot = kv_slot(kv, cache_indices, max_pages, b, key);
+                    kraw[it][e] = *reinterpret_cast<const uint4*>(kbase + (slot * kv.sN + c * CH) * ELT);
+                    vraw[it][e] = *reinterpret_cast<const uint4*>(vbase + (slot * kv.sN + c * CH) * ELT);
+                    if constexpr (QBIT == 8) {
+                        ksc[it][e] = *reinterpret_cast<const uint32_t*>(ksbase + slot * kv.ssN + c * 2);
+                        vsc[it][e] = *reinterpret_cast<const uint32_t*>(vsbase + slot * kv.ssN + c * 2);
+                    }
+                }
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < IPT; ++it) {
+            const int item = threadIdx.x + it * PF_THREADS;
+            if (item < NITEMS) {
+                const int c = item % LPT, kp = item / LPT;
+                const int ch0 = c * CH;
+                float kf[2][CH], vf[2][CH];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    if constexpr (QBIT == 8) {
+                        const uint32_t kw[4] = {kraw[it][e].x, kraw[it][e].y, kraw[it][e].z, kraw[it][e].w};
+                        const uint32_t vw[4] = {vraw[it][e].x, vraw[it][e].y, vraw[it][e].z, vraw[it][e].w};
+#pragma unroll
+                        for (int gi = 0; gi < 2; ++gi) {
+                            const float ks_ = h2f((uint16_t)(ksc[it][e] >> (16 * gi)));
+                            const float vs_ = h2f((uint16_t)(vsc[it][e] >> (16 * gi)));
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const int idx = gi * 8 + i;
+                                kf[e][idx] = (float)(int8_t)(kw[idx >> 2] >> (8 * (idx & 3))) * ks_;
+                                vf[e][idx] = (float)(int8_t)(vw[idx >> 2] >> (8 * (idx & 3))) * vs_;
+                            }
+                        }
+                    } else {
+                        unpack8(kraw[it][e], kf[e]);
+                        unpack8(vraw[it][e], vf[e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int key = 2 * kp + e;
+#pragma unroll
+                    for (int cc = 0; cc < CH / 8; ++cc) {
+                        const int chunk = (ch0 / 8 + cc) ^ k_swz<D>(key);
+                        *reinterpret_cast<uint4*>(&Ks[key * D + chunk * 8]) = pack8(&kf[e][cc * 8]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    const int ch = ch0 + i;
+                    const h2 pr = {(_Float16)vf[0][i], (_Float16)vf[1][i]};
+                    Vt[ch * PF_VS + (kp ^ v_swz(ch))] = __builtin_bit_cast(uint32_t, pr);
+                }
+            }
+        }
+    };
+
+    load_tile(0);
     for (int tile = 0; tile < ntiles; ++tile) {
         const int64_t key0 = (int64_t)tile * PF_BN;
-        // ---- stage K (row-major, swizzled) and V (transposed) ----------------------------------------
-        for (int item = threadIdx.x; item < 32 * LPT; item += 256) {
-            const int c = item % LPT, kp = item / LPT;
-            const int ch0 = c * CH;
-            float kf[2][CH], vf[2][CH];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                int64_t key = key0 + 2 * kp + e;
-                if (key >= kv_end) key = kv_end - 1;
-                const int64_t slot = kv_slot(kv, cache_indices, max_pages, b, key);
-                const uint4 kr = *reinterpret_cast<const uint4*>(kbase + (slot * kv.sN + ch0) * ELT);
-                const uint4 vr = *reinterpret_cast<const uint4*>(vbase + (slot * kv.sN + ch0) * ELT);
-                if constexpr (QBIT == 8) {
-                    const uint32_t kw[4] = {kr.x, kr.y, kr.z, kr.w}, vw[4] = {vr.x, vr.y, vr.z, vr.w};
-#pragma unroll
-                    for (int gi = 0; gi < 2; ++gi) {
-                        const float ks_ = h2f(ksbase[slot * kv.ssN + ch0 / 8 + gi]);
-                        const float vs_ = h2f(vsbase[slot * kv.ssN + ch0 / 8 + gi]);
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const int idx = gi * 8 + i;
-                            kf[e][idx] = (float)(int8_t)(kw[idx >> 2] >> (8 * (idx & 3))) * ks_;
-                            vf[e][idx] = (float)(int8_t)(vw[idx >> 2] >> (8 * (idx & 3))) * vs_;
-                        }
-                    }
-                } else {
-                    unpack8(kr, kf[e]);
-                    unpack8(vr, vf[e]);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int key = 2 * kp + e;
-#pragma unroll
-                for (int cc = 0; cc < CH / 8; ++cc) {
-                    const int chunk = (ch0 / 8 + cc) ^ k_swz<D>(key);
-                    *reinterpret_cast<uint4*>(&Ks[key * D + chunk * 8]) = pack8(&kf[e][cc * 8]);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                const int ch = ch0 + i;
-                const h2 pr = {(_Float16)vf[0][i], (_Float16)vf[1][i]};
-                Vt[ch * PF_VS + (kp ^ v_swz(ch))] = __builtin_bit_cast(uint32_t, pr);
-            }
-        }
+        store_tile();
         __syncthreads();
+        if (tile + 1 < ntiles) load_tile(tile + 1);  // in flight during the MFMAs below
 
-        // ---- S^T = K . Q^T : 4 key tiles of 16 --------------------------------------------------------
-        f4 sacc[4];
+        // a wave whose rows all end before this tile starts has nothing to add (causal)
+        if (wave_active && key0 <= sp + ((q0 + wave * 16 + 15 < seqlen - 1) ? q0 + wave * 16 + 15 : seqlen - 1)) {
+            // ---- S^T = K . Q^T : 8 key tiles of 16 ---------------------------------------------------------
+            f4 sacc[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sacc[j] = f4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 8; ++j) sacc[j] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
+            for (int ks = 0; ks < KSTEPS; ++ks) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int key = j * 16 + l15;
-                const int chunk = (ks * 4 + kq) ^ k_swz<D>(key);
-                const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&Ks[key * D + chunk * 8]));
-                sacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[ks], sacc[j], 0, 0, 0);
+                for (int j = 0; j < 8; ++j) {
+                    const int key = j * 16 + l15;
+                    const int chunk = (ks * 4 + kq) ^ k_swz<D>(key);
+                    const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&Ks[key * D + chunk * 8]));
+                    sacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[ks], sacc[j], 0, 0, 0);
+                }
             }
-        }
-        // ---- online softmax for query row l15; this lane holds keys j*16 + kq*4 + r ---------------------
-        float p[4][4];
-        float mx = -1e30f;
+            // ---- online softmax for query row l15; this lane holds keys j*16 + kq*4 + r ---------------------
+            float mx = -1e30f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t kpos = key0 + j * 16 + kq * 4 + r;
-                const float sv = (kpos <= qpos) ? sacc[j][r] * sm_scale : -1e30f;
-                p[j][r] = sv;
-                mx = fmaxf(mx, sv);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mnew = fmaxf(m, mx);
-        const float alpha = __expf(m - mnew);
-        m = mnew;
-        float rs = 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t kpos = key0 + j * 16 + kq * 4 + r;
+                    const float sv = (kpos <= qpos) ? sacc[j][r] * sm_scale : -1e30f;
+                    sacc[j][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(m, mx);
+            const float alpha = __expf(m - mnew);
+            m = mnew;
+            float rs = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t kpos = key0 + j * 16 + kq * 4 + r;
-                const float e = (kpos <= qpos) ? __expf(p[j][r] - mnew) : 0.f;
-                p[j][r] = e;
-                rs += e;
-            }
-        rs += __shfl_xor(rs, 16, 64);
-        rs += __shfl_xor(rs, 32, 64);
-        l = l * alpha + rs;
-        // rescale O: its C layout has rows (kq*4 + r) -> fetch alpha of those query rows
-        float ar[4];
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t kpos = key0 + j * 16 + kq * 4 + r;
+                    const float e = (kpos <= qpos) ? __expf(sacc[j][r] - mnew) : 0.f;
+                    sacc[j][r] = e;
+                    rs += e;
+                }
+            rs += __shfl_xor(rs, 16, 64);
+            rs += __shfl_xor(rs, 32, 64);
+            l = l * alpha + rs;
+            // rescale O: its C layout has rows (kq*4 + r) -> fetch alpha of those query rows
+            float ar[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, kq * 4 + r, 64);
+            for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, kq * 4 + r, 64);
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[dt][r] *= ar[r];
-        // ---- O += P . V : A = P (this lane's 8 keys per k-step: tiles 2s, 2s+1), B = V^T from LDS ---------
+                for (int r = 0; r < 4; ++r) o[dt][r] *= ar[r];
+            // ---- O += P . V : A = P (this lane's 8 keys per k-step: tiles 2s, 2s+1), B = V^T from LDS ---------
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            h8 pa;
+            for (int s2 = 0; s2 < 4; ++s2) {
+                h8 pa;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                pa[r] = (_Float16)p[2 * s2][r];
-                pa[4 + r] = (_Float16)p[2 * s2 + 1][r];
-            }
+                for (int r = 0; r < 4; ++r) {
+                    pa[r] = (_Float16)sacc[2 * s2][r];
+                    pa[4 + r] = (_Float16)sacc[2 * s2 + 1][r];
+                }
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const int ch = dt * 16 + l15;
-                const int p0 = (8 * (2 * s2) + kq * 2) ^ v_swz(ch);      // dword index of keys 16*(2s)+kq*4
-                const int p1 = (8 * (2 * s2 + 1) + kq * 2) ^ v_swz(ch);
-                const uint2 lo = *reinterpret_cast<const uint2*>(&Vt[ch * PF_VS + p0]);
-                const uint2 hi = *reinterpret_cast<const uint2*>(&Vt[ch * PF_VS + p1]);
-                const h8 bv = __builtin_bit_cast(h8, make_uint4(lo.x, lo.y, hi.x, hi.y));
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, bv, o[dt], 0, 0, 0);
+                for (int dt = 0; dt < DT; ++dt) {
+                    const int ch = dt * 16 + l15;
+                    const int p0 = (8 * (2 * s2) + kq * 2) ^ v_swz(ch);      // dword index of keys 16*(2s)+kq*4
+                    const int p1 = (8 * (2 * s2 + 1) + kq * 2) ^ v_swz(ch);
+                    const uint2 lo = *reinterpret_cast<const uint2*>(&Vt[ch * PF_VS + p0]);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(&Vt[ch * PF_VS + p1]);
+                    const h8 bv = __builtin_bit_cast(h8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, bv, o[dt], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
@@ -228,8 +267,8 @@ hipError_t launch_attn_prefill(hipStream_t s, const uint16_t* qkv, const KvAddr&
     dim3 grid((unsigned)((max_seq_len + PF_BM - 1) / PF_BM), (unsigned)(B - b0), (unsigned)H);
 #define PF_CASE(QB, DD)                                                                                          \
     if (quant_bit == QB && D == DD) {                                                                            \
-        hipLaunchKernelGGL((attn_prefill_kernel<QB, DD>), grid, dim3(256), 0, s, qkv, kv, seq_starts, start_pos, \
-                           cache_indices, max_pages, b0, H, Hkv, out);                                           \
+        hipLaunchKernelGGL((attn_prefill_kernel<QB, DD>), grid, dim3(PF_THREADS), 0, s, qkv, kv, seq_starts,     \
+                           start_pos, cache_indices, max_pages, b0, H, Hkv, out);                                \
         return hipGetLastError();                                                                                \
     }
     PF_CASE(8, 128) PF_CASE(0, 128) PF_CASE(8, 64) PF_CASE(0, 64) PF_CASE(8, 32) PF_CASE(0, 32)
