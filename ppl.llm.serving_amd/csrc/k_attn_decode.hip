@@ -15,6 +15,7 @@
 //   folded out algebraically (sum(q) and sum(p*scale) corrections) -- the per-group fp16 scale multiplies the
 //   8-channel partial dot product, not each element.
 // Numerics: fp32 everywhere, output rounded to fp16 once.  Oracle: ref_attention (oracle/llama_ref.c).
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace pplhip {
@@ -280,6 +281,19 @@ hipError_t launch_attn_decode(hipStream_t s, const uint16_t* qkv, const KvAddr& 
     if (threads < 64 || threads > 64 * DEC_MAX_WAVES || threads % 64) return hipErrorInvalidValue;
     if (threads < D) threads = D;  // the final merge uses one thread per channel
     if (split < 1) split = 1;
+    // grouped-query models: the MFMA kernel (k_attn_prefill.hip) reads each KV row once for the whole head group
+    static const bool no_gqa = getenv("PPLHIP_ATTN_NOGQA") != nullptr;
+    const int grp = H / Hkv;
+    if (grp >= 4 && grp <= 16 && !no_gqa) {
+        hipError_t e = launch_attn_decode_gqa(s, qkv, kv, quant_bit, seq_starts, start_pos, cache_indices, max_pages, nb, H,
+                                              Hkv, D, split, workspace, out);
+        if (e != hipSuccess || split == 1) return e;
+        const dim3 rg((unsigned)(nb * H)), rb(D < 64 ? 64 : D);
+        if (D == 128) hipLaunchKernelGGL((attn_decode_reduce_kernel<128>), rg, rb, 0, s, workspace, split, out);
+        else if (D == 64) hipLaunchKernelGGL((attn_decode_reduce_kernel<64>), rg, rb, 0, s, workspace, split, out);
+        else hipLaunchKernelGGL((attn_decode_reduce_kernel<32>), rg, rb, 0, s, workspace, split, out);
+        return hipGetLastError();
+    }
 #define DEC_CASE(QB, DD)                                                                                            \
     if (quant_bit == QB && D == DD)                                                                                 \
         return launch_decode_t<QB, DD>(s, qkv, kv, seq_starts, start_pos, cache_indices, max_pages, nb, H, Hkv,     \

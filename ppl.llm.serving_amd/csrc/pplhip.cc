@@ -206,7 +206,8 @@ void prof_end(Rank& R, ProfEvent* ev) {
 int decode_split(const pplhip_ctx* c, int64_t nb, int64_t max_kv_len) {
     const int mode = c->o.decoding_attn_split_k;
     if (mode == 0) return 1;
-    const int64_t blocks = nb * c->H;
+    const int grp = c->H / c->Hkv;
+    const int64_t blocks = nb * ((grp >= 4 && grp <= 16) ? c->Hkv : c->H);  // GQA kernel: one block per KV head
     int split = 1;
     // measured (profiles/attn_microbench.py): 512 workgroups already stream at 5.3 TB/s; split only below ~256
     if (mode == 2 || (blocks < 256 && max_kv_len >= 512)) {

@@ -235,7 +235,7 @@ def test_rope_kv_write(quant, layout, mode, H, Hkv, D):
         assert (got_cache == case.cache).all()
 
 
-ATT_SHAPES = [(4, 4, 32), (8, 2, 64), (4, 4, 128), (8, 1, 128)]
+ATT_SHAPES = [(4, 4, 32), (8, 2, 64), (4, 4, 128), (8, 1, 128), (16, 1, 64), (12, 2, 128)]
 
 
 @pytest.mark.parametrize("quant", [0, 8])
