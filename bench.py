@@ -113,16 +113,36 @@ def dry_run(args, P, dist, rank, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
-        print(json.dumps({"metric": "decode tokens/sec, LLaMA-7B int8 (W8A16), max-running-batch 1024", "value": 0.0,
+        emit({"metric": "decode tokens/sec, LLaMA-7B int8 (W8A16), max-running-batch 1024", "value": 0.0,
                           "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4), "higher_is_better": True,
                           "scaling": "strong", "vs_baseline": None, "dry_run": True, "unique_id_agreed": agreed,
-                          "config": {"workload": "dry run (no device work)", "parallelism": f"tp{world}"}}), flush=True)
+                          "config": {"workload": "dry run (no device work)", "parallelism": f"tp{world}"}})
     if dist is not None:
         dist.destroy_process_group()
 
 
+_JSON_OUT = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Native libraries (the RCCL version banner, for one) write to file
+    descriptor 1 through their own stdio buffers, which are flushed at exit -- after our line.  Keep a private copy of
+    the real stdout for the JSON line and point fd 1 at stderr for everything else."""
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    _JSON_OUT.write(json.dumps(obj) + "\n")
+    _JSON_OUT.flush()
+
+
 def main():
+    claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
@@ -170,6 +190,8 @@ def main():
         box = [P.get_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         uid = box[0]
+    elif os.environ.get("PPLHIP_FORCE_COMM"):
+        uid = P.get_unique_id()  # single-GPU self-test of the RCCL path (world size 1: every collective is an identity)
     ctx = P.Context(desc, max_running_batch=B, max_tokens_per_step=max(8192, B), n_local_ranks=1, world_size=world,
                     rank_base=rank, device_ids=[local_rank], unique_id=uid, profiling=True, tpb=args.tpb)
     ctx.init_synthetic(0, 1234)
@@ -274,7 +296,7 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(mk, args.kv_len)
             except Exception as e:  # the baseline is reporting only; never hide the GPU result
                 res["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(res), flush=True)
+        emit(res)
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

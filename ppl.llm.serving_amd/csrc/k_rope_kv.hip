@@ -43,9 +43,9 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(uint16_t* __restrict
                                                             KvAddr kv, const int64_t* __restrict__ seq_starts,
                                                             const int64_t* __restrict__ start_pos,
                                                             const int64_t* __restrict__ cache_indices, int64_t max_pages,
-                                                            int64_t B, int H, int Hkv, int D) {
+                                                            int64_t B, int64_t t0, int H, int Hkv, int D) {
     __shared__ int64_t sh_b;
-    const int64_t t = blockIdx.x;
+    const int64_t t = t0 + blockIdx.x;
     if (threadIdx.x == 0) {  // request of row t: last b with seq_starts[b] <= t
         int64_t lo = 0, hi = B - 1;
         while (lo < hi) {
@@ -100,16 +100,16 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(uint16_t* __restrict
 
 hipError_t launch_rope_kv_write(hipStream_t s, uint16_t* qkv, const float* cos_sin, const KvAddr& kv, int quant_bit,
                                 int quant_group, const int64_t* seq_starts, const int64_t* start_pos,
-                                const int64_t* cache_indices, int64_t max_pages, int64_t B, int64_t T, int H, int Hkv,
-                                int D) {
+                                const int64_t* cache_indices, int64_t max_pages, int64_t B, int64_t t0, int64_t T, int H,
+                                int Hkv, int D) {
     if (T == 0) return hipSuccess;
     if (D % 16 || (quant_bit == 8 && quant_group != 8) || (quant_bit != 0 && quant_bit != 8)) return hipErrorInvalidValue;
     if (quant_bit == 8)
         hipLaunchKernelGGL(rope_kv_write_kernel<8>, dim3((unsigned)T), dim3(256), 0, s, qkv, cos_sin, kv, seq_starts,
-                           start_pos, cache_indices, max_pages, B, H, Hkv, D);
+                           start_pos, cache_indices, max_pages, B, t0, H, Hkv, D);
     else
         hipLaunchKernelGGL(rope_kv_write_kernel<0>, dim3((unsigned)T), dim3(256), 0, s, qkv, cos_sin, kv, seq_starts,
-                           start_pos, cache_indices, max_pages, B, H, Hkv, D);
+                           start_pos, cache_indices, max_pages, B, t0, H, Hkv, D);
     return hipGetLastError();
 }
 

@@ -20,8 +20,8 @@ hipError_t launch_silu_mul(hipStream_t s, const uint16_t* gate_up, int64_t T, in
 // ---- k_rope_kv.hip ----------------------------------------------------------------------------
 hipError_t launch_rope_kv_write(hipStream_t s, uint16_t* qkv, const float* cos_sin, const KvAddr& kv, int quant_bit,
                                 int quant_group, const int64_t* seq_starts, const int64_t* start_pos,
-                                const int64_t* cache_indices, int64_t max_pages, int64_t B, int64_t T, int H, int Hkv,
-                                int D);
+                                const int64_t* cache_indices, int64_t max_pages, int64_t B, int64_t t0, int64_t T, int H,
+                                int Hkv, int D);  // token rows [t0, t0 + T) of the step's B requests
 
 // ---- k_attn_decode.hip ------------------------------------------------------------------------
 // rows [0, nb) of the batch are single-token queries; q row of request b is qkv row seq_starts[b].

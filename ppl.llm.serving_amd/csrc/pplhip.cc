@@ -25,9 +25,14 @@ namespace {
 
 struct Linear {
     int N = 0, K = 0, qbit = 0, group = 0;
+    int Kp = 0;  // row stride on the device: K rounded up to the GEMM k-tile (64) with zero columns, so that a tensor-
+                 // parallel slice like 11008 / 8 = 1376 still runs on the DMA tile kernels (the activation operand is
+                 // padded with zeros to the same stride)
     void* w = nullptr;
     uint16_t* scale = nullptr;
-    uint64_t w_bytes() const { return qbit == 0 ? (uint64_t)N * K * 2 : qbit == 8 ? (uint64_t)N * K : (uint64_t)N * K / 2; }
+    uint64_t elt_bytes(uint64_t n) const { return qbit == 0 ? n * 2 : qbit == 8 ? n : n / 2; }
+    uint64_t w_bytes() const { return elt_bytes((uint64_t)N * K); }       // container (unpadded) size
+    uint64_t alloc_bytes() const { return elt_bytes((uint64_t)N * Kp); }  // device size
     uint64_t s_bytes() const { return qbit == 0 ? 0 : qbit == 8 ? (uint64_t)N * 2 : (uint64_t)N * (K / group) * 2; }
 };
 
@@ -47,6 +52,9 @@ struct Rank {
     int global_rank = 0;
     hipStream_t stream = nullptr;
     ncclComm_t comm = nullptr;
+    hipStream_t comm_stream = nullptr;  // collectives of an overlapped step (pplhip_run)
+    hipEvent_t ev_compute[2] = {nullptr, nullptr}, ev_comm[2] = {nullptr, nullptr};
+    const int64_t* h_seq = nullptr;     // host copy of this step's seq_starts (lives in the staging buffer)
     std::string err;
 
     // weights
@@ -104,6 +112,8 @@ struct pplhip_ctx {
     pplhip_model_desc d;
     pplhip_opts o;
     int tp = 1;
+    bool tp_overlap = true;              // PPLHIP_TP_OVERLAP=0 keeps the collectives on the compute stream
+    int64_t tp_overlap_min_tokens = 128; // PPLHIP_TP_OVERLAP_MIN_TOKENS
     int H = 0, Hkv = 0, D = 0, inter = 0, vocab_local = 0;
     std::vector<Rank> ranks;
     std::string err;
@@ -143,19 +153,25 @@ int dev_alloc(pplhip_ctx* c, int r, void** p, uint64_t bytes) {
     return 0;
 }
 
-int linear_alloc(pplhip_ctx* c, int r, Linear* l, int N, int K, int qbit, int group) {
+int linear_alloc(pplhip_ctx* c, int r, Linear* l, int N, int K, int qbit, int group, bool pad_k = false) {
     l->N = N; l->K = K; l->qbit = qbit; l->group = group;
-    int rc = dev_alloc(c, r, &l->w, l->w_bytes());
+    l->Kp = (pad_k && qbit != 4) ? (K + 63) / 64 * 64 : K;
+    int rc = dev_alloc(c, r, &l->w, l->alloc_bytes());
     if (rc) return rc;
+    if (l->Kp != K) {
+        hipError_t e = hipMemset(l->w, 0, l->alloc_bytes());
+        if (e != hipSuccess) return fail(c, r, PPLHIP_DEVICE_RUNTIME_ERROR, std::string("hipMemset: ") + hipGetErrorString(e));
+    }
     return dev_alloc(c, r, (void**)&l->scale, l->s_bytes());
 }
 
 // name -> device buffer of a rank's slice; names: DESIGN.md "weight container"
-bool find_tensor(pplhip_ctx* c, Rank& R, const char* name, void** ptr, uint64_t* bytes) {
+bool find_tensor(pplhip_ctx* c, Rank& R, const char* name, void** ptr, uint64_t* bytes, Linear** lin_out = nullptr) {
+    if (lin_out) *lin_out = nullptr;
     const int hd = c->d.hidden_dim;
     if (!strcmp(name, "tok_embeddings.weight")) { *ptr = R.embed; *bytes = (uint64_t)c->d.vocab_size * hd * 2; return true; }
     if (!strcmp(name, "norm.weight")) { *ptr = R.norm; *bytes = (uint64_t)hd * 2; return true; }
-    if (!strcmp(name, "output.weight")) { *ptr = R.output.w; *bytes = R.output.w_bytes(); return true; }
+    if (!strcmp(name, "output.weight")) { *ptr = R.output.w; *bytes = R.output.w_bytes(); if (lin_out) *lin_out = &R.output; return true; }
     int l = -1;
     char rest[128];
     if (sscanf(name, "layers.%d.%127s", &l, rest) != 2 || l < 0 || l >= c->d.num_layers) return false;
@@ -167,7 +183,7 @@ bool find_tensor(pplhip_ctx* c, Rank& R, const char* name, void** ptr, uint64_t*
     for (auto& t : tab) {
         const size_t nl = strlen(t.n);
         if (strncmp(rest, t.n, nl)) continue;
-        if (!strcmp(rest + nl, ".weight")) { *ptr = t.lin->w; *bytes = t.lin->w_bytes(); return true; }
+        if (!strcmp(rest + nl, ".weight")) { *ptr = t.lin->w; *bytes = t.lin->w_bytes(); if (lin_out) *lin_out = t.lin; return true; }
         if (!strcmp(rest + nl, ".scale") && t.lin->qbit) { *ptr = t.lin->scale; *bytes = t.lin->s_bytes(); return true; }
     }
     return false;
@@ -257,7 +273,13 @@ void pplhip_destroy(pplhip_ctx* c) {
     for (auto& R : c->ranks) {
         hipSetDevice(R.device);
         if (R.stream) hipStreamSynchronize(R.stream);
+        if (R.comm_stream) hipStreamSynchronize(R.comm_stream);
         if (R.comm) ncclCommDestroy(R.comm);
+        if (R.comm_stream) hipStreamDestroy(R.comm_stream);
+        for (int i = 0; i < 2; ++i) {
+            if (R.ev_compute[i]) hipEventDestroy(R.ev_compute[i]);
+            if (R.ev_comm[i]) hipEventDestroy(R.ev_comm[i]);
+        }
         for (auto& e : R.prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
         for (auto& p : R.prof_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
         for (void* p : R.allocs) hipFree(p);
@@ -320,9 +342,14 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
     for (int r = 0; r < n; ++r) devs[r] = opts->device_ids ? opts->device_ids[r] : r;
 
     // communicators (replaces ppl::common::InitNccl, resource_manager.cc:393)
-    if (tp > 1) {
+    // PPLHIP_FORCE_COMM=1: create the communicator and run every collective even at world size 1 (an identity) --
+    // lets a single-GPU box exercise the RCCL call sequence, the communication stream and its event wiring
+    const bool want_comm = tp > 1 || getenv("PPLHIP_FORCE_COMM") != nullptr;
+    if (const char* e = getenv("PPLHIP_TP_OVERLAP")) c->tp_overlap = atoi(e) != 0;
+    if (const char* e = getenv("PPLHIP_TP_OVERLAP_MIN_TOKENS")) c->tp_overlap_min_tokens = std::max(2, atoi(e));
+    if (want_comm) {
         std::vector<ncclComm_t> comms(n);
-        if (tp == n) {
+        if (tp == n && !opts->nccl_unique_id) {
             NCCLCK(cp, -1, ncclCommInitAll(comms.data(), n, devs.data()));
         } else {
             if (!opts->nccl_unique_id) return fail(cp, -1, PPLHIP_INVALID_VALUE, "nccl_unique_id required when world_size > n_local_ranks");
@@ -350,6 +377,13 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
         R.global_rank = opts->rank_base + r;
         HIPCK(cp, r, hipSetDevice(R.device));
         HIPCK(cp, r, hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
+        if (R.comm) {
+            HIPCK(cp, r, hipStreamCreateWithFlags(&R.comm_stream, hipStreamNonBlocking));
+            for (int i = 0; i < 2; ++i) {
+                HIPCK(cp, r, hipEventCreateWithFlags(&R.ev_compute[i], hipEventDisableTiming));
+                HIPCK(cp, r, hipEventCreateWithFlags(&R.ev_comm[i], hipEventDisableTiming));
+            }
+        }
         int rc;
 #define ALLOC(ptr, bytes) if ((rc = dev_alloc(cp, r, (void**)&(ptr), (uint64_t)(bytes)))) return rc
         ALLOC(R.embed, (uint64_t)d.vocab_size * hd * 2);
@@ -363,7 +397,7 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
             if ((rc = linear_alloc(cp, r, &L.wqkv, (c->H + 2 * c->Hkv) * c->D, hd, q, g))) return rc;
             if ((rc = linear_alloc(cp, r, &L.wo, hd, c->H * c->D, q, g))) return rc;
             if ((rc = linear_alloc(cp, r, &L.w13, 2 * c->inter, hd, q, g))) return rc;
-            if ((rc = linear_alloc(cp, r, &L.w2, hd, c->inter, q, g))) return rc;
+            if ((rc = linear_alloc(cp, r, &L.w2, hd, c->inter, q, g, /*pad_k=*/true))) return rc;
         }
         ALLOC(R.rope, rope.size() * sizeof(float));
         HIPCK(cp, r, hipMemcpy(R.rope, rope.data(), rope.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -384,10 +418,12 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
         ALLOC(R.att, (uint64_t)cap_T * c->H * c->D * 2);
         ALLOC(R.part, (uint64_t)cap_T * hd * 2);
         ALLOC(R.part2, (uint64_t)cap_T * hd * 2);
-        ALLOC(R.act, (uint64_t)cap_T * c->inter * 2);
+        const int inter_p = (d.weight_quant_bit != 4) ? (c->inter + 63) / 64 * 64 : c->inter;  // = layers[*].w2.Kp
+        ALLOC(R.act, (uint64_t)cap_T * inter_p * 2);
+        if (inter_p != c->inter) HIPCK(cp, r, hipMemset(R.act, 0, (uint64_t)cap_T * inter_p * 2));  // pad columns stay zero
         ALLOC(R.hn, (uint64_t)cap_B * hd * 2);
         ALLOC(R.logits, (uint64_t)cap_B * d.vocab_size * 4);
-        if (tp > 1) {
+        if (R.comm) {
             ALLOC(R.logits_local, (uint64_t)cap_B * c->vocab_local * 4);
             ALLOC(R.logits_gather, (uint64_t)cap_B * d.vocab_size * 4);
         }
@@ -421,7 +457,8 @@ int pplhip_rank_set_tensor(pplhip_ctx* c, int rank, const char* name, const void
     if (!c || rank < 0 || rank >= (int)c->ranks.size() || !name || !data) return PPLHIP_INVALID_VALUE;
     Rank& R = c->ranks[rank];
     void* p; uint64_t b;
-    if (!find_tensor(c, R, name, &p, &b)) return fail(c, rank, PPLHIP_NOT_FOUND, std::string("unknown tensor ") + name);
+    Linear* lin = nullptr;
+    if (!find_tensor(c, R, name, &p, &b, &lin)) return fail(c, rank, PPLHIP_NOT_FOUND, std::string("unknown tensor ") + name);
     if (b != bytes) return fail(c, rank, PPLHIP_INVALID_VALUE, std::string("tensor ") + name + ": got " + std::to_string(bytes) + " bytes, want " + std::to_string(b));
     HIPCK(c, rank, hipSetDevice(R.device));
     const char* w13 = strstr(name, "feed_forward.w13.");
@@ -436,6 +473,11 @@ int pplhip_rank_set_tensor(pplhip_ctx* c, int rank, const char* name, const void
         if (e == hipSuccess) e = hipStreamSynchronize(R.stream);
         hipFree(tmp);
         if (e != hipSuccess) return fail(c, rank, PPLHIP_DEVICE_RUNTIME_ERROR, std::string("interleave w13: ") + hipGetErrorString(e));
+        return 0;
+    }
+    if (lin && lin->Kp != lin->K) {  // zero-padded rows (linear_alloc cleared the buffer)
+        const size_t rb = (size_t)lin->elt_bytes(lin->K), rbp = (size_t)lin->elt_bytes(lin->Kp);
+        HIPCK(c, rank, hipMemcpy2D(p, rbp, data, rb, rb, lin->N, hipMemcpyHostToDevice));
         return 0;
     }
     HIPCK(c, rank, hipMemcpy(p, data, bytes, hipMemcpyHostToDevice));
@@ -512,7 +554,17 @@ int pplhip_rank_init_synthetic(pplhip_ctx* c, int rank, uint64_t seed) {
             hipFree(tmp.w);
             if (tmp.scale) hipFree(tmp.scale);
         }
-        HIPCK(c, rank, lin(L.w2, l, 9));
+        if (L.w2.Kp == L.w2.K) {
+            HIPCK(c, rank, lin(L.w2, l, 9));
+        } else {  // generated contiguous, then copied into the zero-padded rows
+            Linear tmp = L.w2;
+            HIPCK(c, rank, hipMalloc(&tmp.w, L.w2.w_bytes()));
+            HIPCK(c, rank, lin(tmp, l, 9));  // scale goes straight to L.w2.scale (same pointer)
+            const size_t rb = (size_t)L.w2.elt_bytes(L.w2.K), rbp = (size_t)L.w2.elt_bytes(L.w2.Kp);
+            HIPCK(c, rank, hipMemcpy2DAsync(L.w2.w, rbp, tmp.w, rb, rb, L.w2.N, hipMemcpyDeviceToDevice, s));
+            HIPCK(c, rank, hipStreamSynchronize(s));
+            hipFree(tmp.w);
+        }
     }
     HIPCK(c, rank, hipStreamSynchronize(s));
     return 0;
@@ -635,7 +687,7 @@ int pplhip_set_inputs(pplhip_ctx* c, int rank, const pplhip_step* st) {
     // packed layout: token_ids[T] | seq_starts[B+1] | kv_starts[B+1] | start_pos[B] | cache_indices[B] (mode 0)
     int64_t off = 0;
     memcpy(hbuf + off, st->token_inputs, T * 8); R.d_tok = R.step_dev + off; off += T;
-    memcpy(hbuf + off, st->seq_starts, (B + 1) * 8); R.d_seq = R.step_dev + off; off += B + 1;
+    memcpy(hbuf + off, st->seq_starts, (B + 1) * 8); R.d_seq = R.step_dev + off; R.h_seq = hbuf + off; off += B + 1;
     memcpy(hbuf + off, st->kv_starts, (B + 1) * 8); R.d_kvs = R.step_dev + off; off += B + 1;
     memcpy(hbuf + off, st->start_pos, B * 8); R.d_sp = R.step_dev + off; off += B;
     if (c->d.cache_mode == 0) {
@@ -669,22 +721,93 @@ int pplhip_set_inputs(pplhip_ctx* c, int rank, const pplhip_step* st) {
     return 0;
 }
 
-static int attention_dispatch(pplhip_ctx* c, int rank, hipStream_t s, const uint16_t* qkv, const KvAddr& kv, int qbit,
-                              const int64_t* seq, const int64_t* sp, const int64_t* ci, int64_t max_pages, int64_t B,
-                              int64_t nb_decode, int64_t max_seq_len, int64_t max_kv_len, int H, int Hkv, int D, int split,
-                              int threads, float* ws, uint16_t* out, Rank* R) {
+// A chunk of a step: requests [b0, b0 + bn) = token rows [t0, t0 + tn); the first nd requests of the chunk are
+// decode rows.  A step runs as ONE chunk, or -- tensor parallel, see pplhip_run -- as two that alternate between the
+// compute stream and the communication stream.
+struct Chunk {
+    int64_t b0, bn, t0, tn, nd;
+};
+
+// attention block of layer l for one chunk: (Skip)RMSNorm -> wqkv -> RoPE + KV write -> attention -> wo (partial sums)
+static int layer_attention_part(pplhip_ctx* c, int rank, int l, const Chunk& k, const uint16_t* pending, int split, int threads) {
+    Rank& R = c->ranks[rank];
+    const pplhip_model_desc& d = c->d;
+    hipStream_t s = R.stream;
+    const int hd = d.hidden_dim, H = c->H, Hkv = c->Hkv, D = c->D;
+    const int nqkv = (H + 2 * Hkv) * D;
+    Layer& L = R.layers[l];
     ProfEvent ev;
-    if (nb_decode > 0) {
-        if (R) prof_begin(c, *R, PPLHIP_PROF_ATTN_DECODE, &ev);
-        HIPCK(c, rank, launch_attn_decode(s, qkv, kv, qbit, seq, sp, ci, max_pages, nb_decode, H, Hkv, D, max_kv_len, split,
-                                          threads, ws, out));
-        if (R) prof_end(*R, &ev);
+    uint16_t* h = R.h + k.t0 * hd;
+    uint16_t* xn = R.xn + k.t0 * hd;
+    HIPCK(c, rank, launch_rmsnorm(s, h, pending ? pending + k.t0 * hd : nullptr, L.attn_norm, d.norm_eps, k.tn, hd, nullptr, xn,
+                                  pending ? h : nullptr));
+    prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
+    HIPCK(c, rank, launch_linear(s, xn, L.wqkv.w, L.wqkv.scale, L.wqkv.qbit, L.wqkv.group, k.tn, L.wqkv.N, L.wqkv.K,
+                                 R.qkv + k.t0 * nqkv, L.wqkv.N, false, R.gemm_ws, R.gemm_ws_bytes));
+    prof_end(R, &ev);
+    const KvAddr kv = make_kv_addr(d, Hkv, D, R.kv_tokens, R.kv_cache, R.kv_scale, l);
+    HIPCK(c, rank, launch_rope_kv_write(s, R.qkv, R.rope, kv, d.cache_quant_bit, d.cache_quant_group, R.d_seq, R.d_sp, R.d_ci,
+                                        R.max_pages, R.B, k.t0, k.tn, H, Hkv, D));
+    // decode rows of the chunk: per-request arrays shifted to the chunk (q rows stay absolute through seq_starts);
+    // prefill requests: absolute request range
+    const int64_t ci_stride = d.cache_mode == 1 ? R.max_pages : 1;
+    if (k.nd > 0) {
+        prof_begin(c, R, PPLHIP_PROF_ATTN_DECODE, &ev);
+        HIPCK(c, rank, launch_attn_decode(s, R.qkv, kv, d.cache_quant_bit, R.d_seq + k.b0, R.d_sp + k.b0, R.d_ci + k.b0 * ci_stride,
+                                          R.max_pages, k.nd, H, Hkv, D, R.max_kv_len, split, threads, R.attn_ws,
+                                          R.att + k.b0 * (int64_t)H * D));
+        prof_end(R, &ev);
     }
-    if (B > nb_decode) {
-        if (R) prof_begin(c, *R, PPLHIP_PROF_ATTN_PREFILL, &ev);
-        HIPCK(c, rank, launch_attn_prefill(s, qkv, kv, qbit, seq, sp, ci, max_pages, nb_decode, B, H, Hkv, D, max_seq_len, out));
-        if (R) prof_end(*R, &ev);
+    if (k.bn > k.nd) {
+        prof_begin(c, R, PPLHIP_PROF_ATTN_PREFILL, &ev);
+        HIPCK(c, rank, launch_attn_prefill(s, R.qkv, kv, d.cache_quant_bit, R.d_seq, R.d_sp, R.d_ci, R.max_pages, k.b0 + k.nd,
+                                           k.b0 + k.bn, H, Hkv, D, R.max_seq_len, R.att));
+        prof_end(R, &ev);
     }
+    prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
+    HIPCK(c, rank, launch_linear(s, R.att + k.t0 * (int64_t)H * D, L.wo.w, L.wo.scale, L.wo.qbit, L.wo.group, k.tn, L.wo.N, L.wo.K,
+                                 R.part + k.t0 * hd, hd, false, R.gemm_ws, R.gemm_ws_bytes));
+    prof_end(R, &ev);
+    return 0;
+}
+
+// feed-forward block of layer l for one chunk: SkipRMSNorm -> w13 with fused SwiGLU (K3 + K10) -> w2 (partial sums)
+static int layer_ffn_part(pplhip_ctx* c, int rank, int l, const Chunk& k) {
+    Rank& R = c->ranks[rank];
+    const pplhip_model_desc& d = c->d;
+    hipStream_t s = R.stream;
+    const int hd = d.hidden_dim;
+    Layer& L = R.layers[l];
+    ProfEvent ev;
+    uint16_t* h = R.h + k.t0 * hd;
+    uint16_t* xn = R.xn + k.t0 * hd;
+    uint16_t* act = R.act + k.t0 * (int64_t)L.w2.Kp;
+    HIPCK(c, rank, launch_rmsnorm(s, h, R.part + k.t0 * hd, L.ffn_norm, d.norm_eps, k.tn, hd, nullptr, xn, h));
+    prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
+    HIPCK(c, rank, launch_linear(s, xn, L.w13.w, L.w13.scale, L.w13.qbit, L.w13.group, k.tn, L.w13.N, L.w13.K, act, L.w2.Kp, false,
+                                 R.gemm_ws, R.gemm_ws_bytes, /*swiglu=*/true));
+    prof_end(R, &ev);
+    prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
+    HIPCK(c, rank, launch_linear(s, act, L.w2.w, L.w2.scale, L.w2.qbit, L.w2.group, k.tn, L.w2.N, L.w2.Kp, R.part2 + k.t0 * hd, hd,
+                                 false, R.gemm_ws, R.gemm_ws_bytes));
+    prof_end(R, &ev);
+    return 0;
+}
+
+// all-reduce(sum) of the chunk's rows of `buf` ([T, hidden] fp16).  Overlapped mode: on the communication stream,
+// after the compute stream's work so far; the compute stream picks the result up through R.ev_comm[ci] later.
+static int chunk_allreduce(pplhip_ctx* c, int rank, uint16_t* buf, const Chunk& k, int ci, bool overlapped) {
+    Rank& R = c->ranks[rank];
+    const int hd = c->d.hidden_dim;
+    uint16_t* p = buf + k.t0 * hd;
+    if (!overlapped) {
+        NCCLCK(c, rank, ncclAllReduce(p, p, (size_t)k.tn * hd, ncclFloat16, ncclSum, R.comm, R.stream));
+        return 0;
+    }
+    HIPCK(c, rank, hipEventRecord(R.ev_compute[ci], R.stream));
+    HIPCK(c, rank, hipStreamWaitEvent(R.comm_stream, R.ev_compute[ci], 0));
+    NCCLCK(c, rank, ncclAllReduce(p, p, (size_t)k.tn * hd, ncclFloat16, ncclSum, R.comm, R.comm_stream));
+    HIPCK(c, rank, hipEventRecord(R.ev_comm[ci], R.comm_stream));
     return 0;
 }
 
@@ -698,58 +821,74 @@ int pplhip_run(pplhip_ctx* c, int rank, int cache_prefill) {
     hipStream_t s = R.stream;
     const int64_t T = R.T, B = R.B;
     if (B == 0) return 0;
-    const int hd = d.hidden_dim, H = c->H, Hkv = c->Hkv, D = c->D, inter = c->inter;
-    int64_t nb_decode = std::min<int64_t>(std::max<int64_t>(R.decoding_batches, 0), B);
-    const int split = nb_decode > 0 ? decode_split(c, nb_decode, R.max_kv_len) : 1;
+    const int hd = d.hidden_dim;
+    const int64_t nb_decode = std::min<int64_t>(std::max<int64_t>(R.decoding_batches, 0), B);
     const int threads = c->o.decoding_attn_tpb == 512 ? 512 : 256;
+    const bool comm = R.comm != nullptr;
+
+    // Tensor parallel: the step is cut at a request boundary into two chunks of about T/2 rows.  While RCCL reduces
+    // the partial sums of one chunk on the communication stream, the compute stream runs the other chunk's block
+    // (attention part or FFN part), so the xGMI time hides under the matmuls instead of adding to them.
+    Chunk ck[2];
+    int nck = 1;
+    ck[0] = Chunk{0, B, 0, T, nb_decode};
+    if (comm && c->tp_overlap && R.h_seq && T >= c->tp_overlap_min_tokens && B >= 2) {
+        int64_t bm = 1;
+        while (bm < B - 1 && R.h_seq[bm] < T / 2) ++bm;  // first request boundary at or after row T/2
+        if (nb_decode == B) {                             // pure decode: whole 128-row GEMM tiles in the first chunk
+            const int64_t r = (T / 2 + 127) / 128 * 128;
+            bm = r < B ? r : B / 2;
+        }
+        const int64_t tm = R.h_seq[bm];
+        ck[0] = Chunk{0, bm, 0, tm, std::min(nb_decode, bm)};
+        ck[1] = Chunk{bm, B - bm, tm, T - tm, std::max<int64_t>(0, nb_decode - bm)};
+        nck = 2;
+    }
+    const bool ov = nck == 2;
+    int split[2] = {1, 1};
+    for (int i = 0; i < nck; ++i) split[i] = ck[i].nd > 0 ? decode_split(c, ck[i].nd, R.max_kv_len) : 1;
+
     ProfEvent ev_run, ev;
     prof_begin(c, R, PPLHIP_PROF_RUN, &ev_run);
-
     HIPCK(c, rank, launch_embedding(s, R.d_tok, R.embed, T, hd, R.h));
     const uint16_t* pending = nullptr;
+    int rc;
     for (int l = 0; l < d.num_layers; ++l) {
-        Layer& L = R.layers[l];
-        HIPCK(c, rank, launch_rmsnorm(s, R.h, pending, L.attn_norm, d.norm_eps, T, hd, nullptr, R.xn, pending ? R.h : nullptr));
-        prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-        HIPCK(c, rank, launch_linear(s, R.xn, L.wqkv.w, L.wqkv.scale, L.wqkv.qbit, L.wqkv.group, T, L.wqkv.N, L.wqkv.K, R.qkv, L.wqkv.N, false, R.gemm_ws, R.gemm_ws_bytes));
-        prof_end(R, &ev);
-        const KvAddr kv = make_kv_addr(d, Hkv, D, R.kv_tokens, R.kv_cache, R.kv_scale, l);
-        HIPCK(c, rank, launch_rope_kv_write(s, R.qkv, R.rope, kv, d.cache_quant_bit, d.cache_quant_group, R.d_seq, R.d_sp,
-                                            R.d_ci, R.max_pages, B, T, H, Hkv, D));
-        int rc = attention_dispatch(c, rank, s, R.qkv, kv, d.cache_quant_bit, R.d_seq, R.d_sp, R.d_ci, R.max_pages, B,
-                                    nb_decode, R.max_seq_len, R.max_kv_len, H, Hkv, D, split, threads, R.attn_ws, R.att, &R);
-        if (rc) return rc;
-        prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-        HIPCK(c, rank, launch_linear(s, R.att, L.wo.w, L.wo.scale, L.wo.qbit, L.wo.group, T, L.wo.N, L.wo.K, R.part, hd, false, R.gemm_ws, R.gemm_ws_bytes));
-        prof_end(R, &ev);
-        if (c->tp > 1) NCCLCK(c, rank, ncclAllReduce(R.part, R.part, (size_t)T * hd, ncclFloat16, ncclSum, R.comm, s));
-        HIPCK(c, rank, launch_rmsnorm(s, R.h, R.part, L.ffn_norm, d.norm_eps, T, hd, nullptr, R.xn, R.h));
-        prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-        HIPCK(c, rank, launch_linear(s, R.xn, L.w13.w, L.w13.scale, L.w13.qbit, L.w13.group, T, L.w13.N, L.w13.K, R.act, inter, false,
-                                     R.gemm_ws, R.gemm_ws_bytes, /*swiglu=*/true));  // K3 + K10 fused
-        prof_end(R, &ev);
-        prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-        HIPCK(c, rank, launch_linear(s, R.act, L.w2.w, L.w2.scale, L.w2.qbit, L.w2.group, T, L.w2.N, L.w2.K, R.part2, hd, false, R.gemm_ws, R.gemm_ws_bytes));
-        prof_end(R, &ev);
-        if (c->tp > 1) NCCLCK(c, rank, ncclAllReduce(R.part2, R.part2, (size_t)T * hd, ncclFloat16, ncclSum, R.comm, s));
+        for (int i = 0; i < nck; ++i) {
+            if (ov && l > 0) HIPCK(c, rank, hipStreamWaitEvent(s, R.ev_comm[i], 0));  // part2 rows of chunk i are reduced
+            if ((rc = layer_attention_part(c, rank, l, ck[i], pending, split[i], threads))) return rc;
+            if (comm && (rc = chunk_allreduce(c, rank, R.part, ck[i], i, ov))) return rc;
+        }
+        for (int i = 0; i < nck; ++i) {
+            if (ov) HIPCK(c, rank, hipStreamWaitEvent(s, R.ev_comm[i], 0));            // part rows of chunk i are reduced
+            if ((rc = layer_ffn_part(c, rank, l, ck[i]))) return rc;
+            if (comm && (rc = chunk_allreduce(c, rank, R.part2, ck[i], i, ov))) return rc;
+        }
         pending = R.part2;
     }
-    // K11: last-token gather + final (Skip)RMSNorm + lm_head (+ all-gather of the vocab shards)
-    if (pending) {
-        // fold the last FFN output into the residual of the gathered rows only
-        HIPCK(c, rank, launch_rmsnorm(s, R.h, pending, R.norm, d.norm_eps, B, hd, R.d_seq, R.hn, nullptr));
-    } else {
-        HIPCK(c, rank, launch_rmsnorm(s, R.h, nullptr, R.norm, d.norm_eps, B, hd, R.d_seq, R.hn, nullptr));
-    }
+    if (ov) for (int i = 0; i < nck; ++i) HIPCK(c, rank, hipStreamWaitEvent(s, R.ev_comm[i], 0));
+    // K11: last-token gather + final (Skip)RMSNorm (the last FFN output is folded into the residual of the gathered
+    // rows only) + lm_head (+ all-gather of the vocab shards)
+    HIPCK(c, rank, launch_rmsnorm(s, R.h, pending, R.norm, d.norm_eps, B, hd, R.d_seq, R.hn, nullptr));
     prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-    if (c->tp == 1) {
+    if (!comm) {
         HIPCK(c, rank, launch_linear(s, R.hn, R.output.w, nullptr, 0, 0, B, R.output.N, hd, R.logits, d.vocab_size, true, R.gemm_ws, R.gemm_ws_bytes));
         prof_end(R, &ev);
     } else {
         const int vl = c->vocab_local;
         HIPCK(c, rank, launch_linear(s, R.hn, R.output.w, nullptr, 0, 0, B, vl, hd, R.logits_local, vl, true, R.gemm_ws, R.gemm_ws_bytes));
         prof_end(R, &ev);
-        NCCLCK(c, rank, ncclAllGather(R.logits_local, R.logits_gather, (size_t)B * vl, ncclFloat32, R.comm, s));
+        // every collective of this communicator is issued on ONE stream (the communication stream when overlapping)
+        hipStream_t cs = ov ? R.comm_stream : s;
+        if (ov) {
+            HIPCK(c, rank, hipEventRecord(R.ev_compute[0], s));
+            HIPCK(c, rank, hipStreamWaitEvent(cs, R.ev_compute[0], 0));
+        }
+        NCCLCK(c, rank, ncclAllGather(R.logits_local, R.logits_gather, (size_t)B * vl, ncclFloat32, R.comm, cs));
+        if (ov) {
+            HIPCK(c, rank, hipEventRecord(R.ev_comm[0], cs));
+            HIPCK(c, rank, hipStreamWaitEvent(s, R.ev_comm[0], 0));
+        }
         for (int r = 0; r < c->tp; ++r)
             HIPCK(c, rank, hipMemcpy2DAsync(R.logits + (size_t)r * vl, (size_t)d.vocab_size * 4, R.logits_gather + (size_t)r * B * vl,
                                             (size_t)vl * 4, (size_t)vl * 4, B, hipMemcpyDeviceToDevice, s));
@@ -930,7 +1069,7 @@ int pplhip_op_rope_kv_write(void* stream, void* qkv, const float* cos_sin, const
                             int32_t num_heads) {
     if (!kv) return PPLHIP_INVALID_VALUE;
     return op_rc(launch_rope_kv_write((hipStream_t)stream, (uint16_t*)qkv, cos_sin, view_addr(kv), kv->quant_bit, kv->quant_group,
-                                      seq_starts, start_pos, cache_indices, max_pages, B, T, num_heads, kv->kv_heads, kv->head_dim));
+                                      seq_starts, start_pos, cache_indices, max_pages, B, 0, T, num_heads, kv->kv_heads, kv->head_dim));
 }
 
 int pplhip_op_attention(void* stream, const void* qkv, const pplhip_kv_view* kv, const int64_t* seq_starts,

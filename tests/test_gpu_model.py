@@ -111,11 +111,13 @@ def test_hf_fixture_model(golden_dir, name, layout, mode, quant):
     ctx.close()
 
 
-@pytest.mark.parametrize("wq,kvq,mode", [(8, 8, 1), (4, 8, 0), (0, 0, 0), (8, 0, 1)])
-def test_synthetic_model(wq, kvq, mode):
-    """synthetic weights generated ON THE DEVICE equal the oracle's generator (else logits could not agree)."""
+@pytest.mark.parametrize("wq,kvq,mode,inter", [(8, 8, 1, 512), (4, 8, 0, 512), (0, 0, 0, 512), (8, 0, 1, 512),
+                                               (8, 8, 0, 176), (0, 0, 1, 336)])
+def test_synthetic_model(wq, kvq, mode, inter):
+    """synthetic weights generated ON THE DEVICE equal the oracle's generator (else logits could not agree).
+    inter % 64 != 0 (a tensor-parallel slice such as 11008 / 8 = 1376) exercises the zero-padded w2 rows."""
     m = load_pplhip()
-    desc = ref.make_desc(hidden_dim=256, intermediate_dim=512, num_layers=2, num_heads=4, num_kv_heads=4, vocab_size=1024,
+    desc = ref.make_desc(hidden_dim=256, intermediate_dim=inter, num_layers=2, num_heads=4, num_kv_heads=4, vocab_size=1024,
                          max_position=512, cache_quant_bit=kvq, cache_quant_group=8 if kvq else 1, cache_layout=3,
                          cache_mode=mode, page_size=16 if mode else 0, weight_quant_bit=wq, weight_quant_group=128)
     rm = ref.RefModel(desc)
@@ -129,6 +131,67 @@ def test_synthetic_model(wq, kvq, mode):
     res = generate_both(m, ctx, [rm], desc, prompts, 4, 1024)
     check_steps(res, k=8 if wq == 4 else 4)
     ctx.close()
+
+
+def test_uploaded_weights_with_padded_w2_rows():
+    """upload path (pplhip_rank_set_tensor) for a slice whose intermediate size is not a multiple of the GEMM k-tile:
+    the oracle's tensors are uploaded byte for byte; w2 lands in zero-padded rows on the device."""
+    m = load_pplhip()
+    desc = ref.make_desc(hidden_dim=256, intermediate_dim=176, num_layers=2, num_heads=4, num_kv_heads=2, vocab_size=512,
+                         max_position=256, cache_quant_bit=8, cache_quant_group=8, cache_layout=3, cache_mode=0,
+                         weight_quant_bit=8)
+    rm = ref.RefModel(desc)
+    rm.init_synthetic(77)
+    ctx = m.Context(m.copy_desc(desc), max_running_batch=8, max_tokens_per_step=128)
+    for name in ref.tensor_names(desc):
+        ctx.set_tensor(0, name, rm.get_tensor(name, np.uint8))
+    rm.kv_alloc(512)
+    ctx.kv_alloc(0, 512)
+    rng = np.random.RandomState(3)
+    prompts = [rng.randint(3, 512, size=n) for n in (33, 2, 65)]
+    check_steps(generate_both(m, ctx, [rm], desc, prompts, 3, 512), k=8)
+    ctx.close()
+
+
+@pytest.mark.parametrize("init", ["all", "unique_id"])
+def test_comm_path_and_chunked_overlap_single_gpu(monkeypatch, init):
+    """PPLHIP_FORCE_COMM=1 builds the RCCL communicator at world size 1 (every collective is an identity) so that the
+    call sequence of the tensor-parallel step -- all-reduce after wo and w2, all-gather of the logits, the
+    communication stream and its events, the two-chunk schedule -- runs on a one-GPU box.  Same logits as the plain
+    path: bit for bit with the collectives on the compute stream, oracle tolerance for the chunked schedule (the
+    chunks may take another GEMM kernel)."""
+    m = load_pplhip()
+    desc = ref.make_desc(hidden_dim=256, intermediate_dim=512, num_layers=3, num_heads=4, num_kv_heads=2, vocab_size=1024,
+                         max_position=512, cache_quant_bit=8, cache_quant_group=8, cache_layout=3, cache_mode=1, page_size=16,
+                         weight_quant_bit=8)
+    rng = np.random.RandomState(11)
+    prompts = [rng.randint(3, 1024, size=n) for n in (40, 3, 129, 1, 16, 77)]
+    rm = ref.RefModel(desc)
+    rm.init_synthetic(99)
+    rm.kv_alloc(2048)
+
+    def run(env):
+        for k in ("PPLHIP_FORCE_COMM", "PPLHIP_TP_OVERLAP", "PPLHIP_TP_OVERLAP_MIN_TOKENS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        uid = m.get_unique_id() if (env and init == "unique_id") else None
+        ctx = m.Context(m.copy_desc(desc), max_running_batch=16, max_tokens_per_step=512, unique_id=uid)
+        ctx.init_synthetic(0, 99)
+        ctx.kv_alloc(0, 2048)
+        rm_kv = rm.kv_array(0); rm_kv[:] = 0
+        res = generate_both(m, ctx, [rm], desc, prompts, 4, 2048)
+        ctx.close()
+        return res
+
+    plain = run({})
+    same_stream = run({"PPLHIP_FORCE_COMM": "1", "PPLHIP_TP_OVERLAP": "0"})
+    chunked = run({"PPLHIP_FORCE_COMM": "1", "PPLHIP_TP_OVERLAP": "1", "PPLHIP_TP_OVERLAP_MIN_TOKENS": "2"})
+    for a, b in zip(plain, same_stream):
+        assert (a[0] == b[0]).all() and (a[2] == b[2]).all()
+    check_steps(chunked, k=8)
+    for a, b in zip(plain, chunked):
+        assert np.abs(a[0] - b[0]).max() <= 4e-3 * max(1.0, np.abs(a[0]).max())
 
 
 def test_container_load_and_errors(golden_dir):
