@@ -156,6 +156,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tpb", type=int, default=0)
     ap.add_argument("--prefill-sample", type=int, default=1, help="also time one 8192-token prefill step (TTFT proxy)")
+    ap.add_argument("--emulate-tp", type=int, default=0,
+                    help="profiling only: run ONE rank's slice of a tp-way step on one GPU (collectives are local "
+                         "identities, logits incomplete); the printed line is marked invalid as a throughput number")
     ap.add_argument("--dry-run", action="store_true",
                     help="no device work: exercises only the multi-process control plane (CPU test of the N>1 path)")
     args = ap.parse_args()
@@ -190,9 +193,12 @@ def main():
         box = [P.get_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         uid = box[0]
+    elif args.emulate_tp > 1:
+        os.environ["PPLHIP_EMULATE_TP"] = "1"
     elif os.environ.get("PPLHIP_FORCE_COMM"):
         uid = P.get_unique_id()  # single-GPU self-test of the RCCL path (world size 1: every collective is an identity)
-    ctx = P.Context(desc, max_running_batch=B, max_tokens_per_step=max(8192, B), n_local_ranks=1, world_size=world,
+    tp = args.emulate_tp if args.emulate_tp > 1 else world
+    ctx = P.Context(desc, max_running_batch=B, max_tokens_per_step=max(8192, B), n_local_ranks=1, world_size=tp,
                     rank_base=rank, device_ids=[local_rank], unique_id=uid, profiling=True, tpb=args.tpb)
     ctx.init_synthetic(0, 1234)
     kv_tokens = B * total_len
@@ -201,7 +207,7 @@ def main():
         sys.exit(f"KV slab needs {kv_tokens} tokens but only {cap} fit")
     ctx.kv_alloc(0, kv_tokens)
     ctx.kv_fill_synthetic(0, 99)
-    H, Hkv, D = desc.num_heads // world, desc.num_kv_heads // world, desc.hidden_dim // desc.num_heads
+    H, Hkv, D = desc.num_heads // tp, desc.num_kv_heads // tp, desc.hidden_dim // desc.num_heads
 
     rng = np.random.RandomState(1234)
     cache_idx = (np.arange(B, dtype=np.int64) * total_len)
@@ -250,6 +256,8 @@ def main():
         except Exception:
             traffic = None
 
+    if tp > 1:
+        traffic = None  # the PMC figure was collected for the single-GPU launch shape only
     extra = {}
     if args.prefill_sample:
         # TTFT proxy: one admission step of 16 x 512-token prompts (max_tokens_per_step 8192), cold cache slots
@@ -291,6 +299,8 @@ def main():
         res.update(extra)
         if args.layers:
             res["INVALID"] = "layer count overridden for debugging"
+        if args.emulate_tp > 1:
+            res["INVALID"] = f"one rank's slice of a tp{args.emulate_tp} step without its peers (profiling only)"
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(mk, args.kv_len)

@@ -113,7 +113,12 @@ struct pplhip_ctx {
     pplhip_opts o;
     int tp = 1;
     bool tp_overlap = true;              // PPLHIP_TP_OVERLAP=0 keeps the collectives on the compute stream
-    int64_t tp_overlap_min_tokens = 128; // PPLHIP_TP_OVERLAP_MIN_TOKENS
+    // PPLHIP_TP_OVERLAP_MIN_TOKENS.  Measured on one MI355X with identity collectives (bench.py --emulate-tp 2/4/8,
+    // profiles/r01_tp_emulation.txt): the two-chunk schedule costs a 1024-row decode step +6..7 ms (27 us per
+    // cross-stream hand-off x 128, plus two half-size GEMM launches instead of one) -- about what the 64 all-reduces
+    // of 8 MB it hides are worth -- so it is used for steps that carry prefill tokens (T >= 2048: 16+ MB per
+    // all-reduce, chunks of >= 1024 rows keep the GEMM tiles full), not for pure decode steps of <= 1024 rows.
+    int64_t tp_overlap_min_tokens = 2048;
     int H = 0, Hkv = 0, D = 0, inter = 0, vocab_local = 0;
     std::vector<Rank> ranks;
     std::string err;
@@ -349,7 +354,10 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
     if (const char* e = getenv("PPLHIP_TP_OVERLAP_MIN_TOKENS")) c->tp_overlap_min_tokens = std::max(2, atoi(e));
     if (want_comm) {
         std::vector<ncclComm_t> comms(n);
-        if (tp == n && !opts->nccl_unique_id) {
+        // PPLHIP_EMULATE_TP=1 (measurement only): this process holds n of the tp slices but the communicator spans only
+        // those n, so one GPU can time the per-rank work of a tp-way step (collectives become local identities and the
+        // gathered logits are incomplete)
+        if ((tp == n && !opts->nccl_unique_id) || getenv("PPLHIP_EMULATE_TP")) {
             NCCLCK(cp, -1, ncclCommInitAll(comms.data(), n, devs.data()));
         } else {
             if (!opts->nccl_unique_id) return fail(cp, -1, PPLHIP_INVALID_VALUE, "nccl_unique_id required when world_size > n_local_ranks");
