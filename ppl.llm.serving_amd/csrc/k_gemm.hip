@@ -230,6 +230,18 @@ __device__ __forceinline__ h8 cvt_i8x8_f16(uint2 v) {
     return h8{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
 }
 
+// 8 nibbles (low nibble = even k, value = nibble - 8) -> 8 fp16 in k order, times the group scale: split the even and
+// odd nibbles into bytes, v_perm pairs them up under the fp16 exponent 0x64 (1024 + n, exact), subtract 1032, scale.
+__device__ __forceinline__ h8 cvt_i4x8_f16(uint32_t w, h2 sc) {
+    const uint32_t ev = w & 0x0f0f0f0fu, od = (w >> 4) & 0x0f0f0f0fu;  // bytes: k = 0,2,4,6 / 1,3,5,7
+    const h2 bias = {(_Float16)1032.0f, (_Float16)1032.0f};
+    const h2 a = (__builtin_bit_cast(h2, __builtin_amdgcn_perm(od, ev, 0x0c040c00u) | 0x64006400u) - bias) * sc;
+    const h2 b = (__builtin_bit_cast(h2, __builtin_amdgcn_perm(od, ev, 0x0c050c01u) | 0x64006400u) - bias) * sc;
+    const h2 c = (__builtin_bit_cast(h2, __builtin_amdgcn_perm(od, ev, 0x0c060c02u) | 0x64006400u) - bias) * sc;
+    const h2 d = (__builtin_bit_cast(h2, __builtin_amdgcn_perm(od, ev, 0x0c070c03u) | 0x64006400u) - bias) * sc;
+    return h8{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+}
+
 // LDS-DMA issued from inline asm so that hipcc does not see an outstanding LDS write and does not drain vmcnt(0)
 // in front of the fragment reads of the CURRENT tile (cdna_hip_programming.md 5.7: M0 is written and restored in the
 // same statement; completion is waited for by hand with s_waitcnt vmcnt(0) before the publishing barrier).
@@ -244,18 +256,22 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
 
-template <int WQ, int EPI, int G_ST>  // WQ = 8: int8 weights + per-channel scale; WQ = 0: fp16 weights
+constexpr int W4_MAXG = 64;  // W4: quantisation groups (of 128 along K) whose scales one block keeps in LDS
+
+template <int WQ, int EPI, int G_ST>  // WQ = 8: int8 weights + per-channel scale; WQ = 0: fp16; WQ = 4: int4, group 128
 __global__ __launch_bounds__(256) void gemm_dma_kernel(const uint16_t* __restrict__ x, const void* __restrict__ wv,
                                                              const uint16_t* __restrict__ scale, int64_t M, int N, int K,
                                                              void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles,
                                                              int map_mode, int kt_per_split, float* __restrict__ ws) {
     // ONE __shared__ object (a second one makes hipcc wait vmcnt(0) before every ds_read of a DMA pipeline)
-    constexpr int WB = WQ == 8 ? 1 : 2;                 // bytes per weight element
-    constexpr int W_STAGE = G_BN * G_BK * WB;           // 8 KiB (int8) / 16 KiB (fp16)
-    constexpr int W_DMA = W_STAGE / 4096;               // DMA instructions per wave per tile for W
-    __shared__ __attribute__((aligned(16))) char smem[G_ST * (G_BM * G_BK * 2 + W_STAGE)];  // per stage: X 16 KiB + W
+    constexpr int WB2 = WQ == 8 ? 2 : (WQ == 4 ? 1 : 4);   // half-bytes per weight element
+    constexpr int W_STAGE = G_BN * G_BK * WB2 / 2;         // 8 KiB (int8) / 16 KiB (fp16) / 4 KiB (int4)
+    constexpr int W_DMA = W_STAGE / 4096;                  // DMA instructions per wave per tile for W
+    constexpr int SC_BYTES = WQ == 4 ? W4_MAXG * G_BN * 2 : 0;  // W4: group scales of this block's rows, [group][row]
+    __shared__ __attribute__((aligned(16))) char smem[G_ST * (G_BM * G_BK * 2 + W_STAGE) + SC_BYTES];  // per stage: X 16 KiB + W
     uint16_t* const Xs0 = reinterpret_cast<uint16_t*>(smem);
     char* const Wq0 = smem + G_ST * G_BM * G_BK * 2;
+    uint16_t* const Sc = reinterpret_cast<uint16_t*>(smem + G_ST * (G_BM * G_BK * 2 + W_STAGE));
     const char* w = reinterpret_cast<const char*>(wv);
 
     // block -> tile.  map_mode 1 (m_tiles % 8 == 0): XCD x = id % 8 owns the activation row-tiles m == x (mod 8) and
@@ -301,6 +317,13 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const uint16_t* __restric
             int n = n0 + row;
             if (n >= N) n = N - 1;
             wsrc[j] = w + (int64_t)n * K + c * 16;
+        } else if constexpr (WQ == 4) {
+            // 32-byte rows (64 nibbles): lane (row, kq) later reads bytes [kq*8, kq*8+8) = its k range kq*16 .. +16;
+            // rows with bit 3 set swap their 16-byte halves so that rows r and r+8 do not share LDS banks
+            const int row = p >> 1, c = (p & 1) ^ ((row >> 3) & 1);
+            int n = n0 + row;
+            if (n >= N) n = N - 1;
+            wsrc[j] = w + ((int64_t)n * K) / 2 + c * 16;
         } else {  // fp16 weights: staged exactly like the activation tile
             const int row = p >> 3, pos = (p & 7) ^ ((row >> 1) & 7);
             const int c = ((pos & 3) << 1) | (pos >> 2);
@@ -316,7 +339,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const uint16_t* __restric
 #pragma unroll
         for (int j = 0; j < 4; ++j) glds16(xsrc[j] + k0, xdst + stage * (G_BM * G_BK * 2) + j * 4096);
 #pragma unroll
-        for (int j = 0; j < W_DMA; ++j) glds16(wsrc[j] + k0 * WB, wdst + stage * W_STAGE + j * 4096);
+        for (int j = 0; j < W_DMA; ++j) glds16(wsrc[j] + k0 * WB2 / 2, wdst + stage * W_STAGE + j * 4096);
     };
 
     f4 acc[4][4];
@@ -334,13 +357,30 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const uint16_t* __restric
     const int kt_all = K / G_BK;
     const int kt0 = blockIdx.y * kt_per_split;
     const int ktiles = (kt0 + kt_per_split < kt_all) ? kt_per_split : kt_all - kt0;
+    if constexpr (WQ == 4) {
+        // group scales of this block's 128 rows over its K range -> LDS, transposed to [group][row] (one 32-byte run per
+        // 16-lane fragment read); kt0 and kt_per_split are even (launcher), so a group never straddles two splits
+        const int G = K / 128, g0 = kt0 >> 1, ng = (ktiles + 1) >> 1;
+        for (int e = tid; e < ng * G_BN; e += 256) {
+            const int row = e / ng, g = e - row * ng;
+            int n = n0 + row;
+            if (n >= N) n = N - 1;
+            Sc[g * G_BN + row] = scale[(int64_t)n * G + g0 + g];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // before the counted DMA pipeline starts
+    }
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (d < ktiles) issue(d, (kt0 + d) * G_BK);
     int st = 0, stn = D;  // stage of tile t, stage of tile t+D
+    h2 gsc[4];            // W4: this lane's four row scales of the current group
     for (int t = 0; t < ktiles; ++t) {
         const int younger = (ktiles - 1 - t) < (D - 1) ? (ktiles - 1 - t) : (D - 1);
-        if constexpr (WQ == 8) {  // 6 DMA instructions per wave per tile
+        if constexpr (WQ == 4) {  // 5 DMA instructions per wave per tile
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if constexpr (WQ == 8) {  // 6 DMA instructions per wave per tile
             if (younger >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             else if (younger == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -363,6 +403,20 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const uint16_t* __restric
                 const int row = wn * 64 + i * 16 + l15;
                 wraw[i] = *reinterpret_cast<const uint4*>(&wq[row * G_BK + (kq ^ w_swz(row)) * 16]);
             }
+        } else if constexpr (WQ == 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wn * 64 + i * 16 + l15;
+                const uint2 v = *reinterpret_cast<const uint2*>(&wq[row * 32 + ((kq ^ (((row >> 3) & 1) << 1)) * 8)]);
+                wraw[i].x = v.x; wraw[i].y = v.y;
+            }
+            if ((t & 1) == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const _Float16 sv = __builtin_bit_cast(_Float16, Sc[(t >> 1) * G_BN + wn * 64 + i * 16 + l15]);
+                    gsc[i] = h2{sv, sv};
+                }
+            }
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -371,6 +425,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const uint16_t* __restric
             for (int i = 0; i < 4; ++i) {
                 if constexpr (WQ == 8) {
                     a[i] = cvt_i8x8_f16(ks == 0 ? make_uint2(wraw[i].x, wraw[i].y) : make_uint2(wraw[i].z, wraw[i].w));
+                } else if constexpr (WQ == 4) {
+                    a[i] = cvt_i4x8_f16(ks == 0 ? wraw[i].x : wraw[i].y, gsc[i]);
                 } else {
                     const int row = wn * 64 + i * 16 + l15;
                     a[i] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&wq[(row * G_BK + g_swz(row, ks * 4 + kq) * 8) * 2]));
@@ -706,7 +762,10 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
 #undef L256
         return hipGetLastError();
     }
-    if ((wq_bit == 8 || wq_bit == 0) && K % G_BK == 0 && !getenv("PPLHIP_GEMM_GENERIC")) {
+    // W4: group 128 = two K tiles; one block keeps at most W4_MAXG groups of scales in LDS
+    const bool w4_fast = wq_bit == 4 && group == 128 && K % 128 == 0 &&
+                         (K / 128 <= W4_MAXG || (ws && (size_t)((K / 128 + W4_MAXG - 1) / W4_MAXG) * M * N * sizeof(float) <= ws_bytes));
+    if ((wq_bit == 8 || wq_bit == 0 || w4_fast) && K % G_BK == 0 && !getenv("PPLHIP_GEMM_GENERIC")) {
         static const int forced = getenv("PPLHIP_GEMM_MAP") ? atoi(getenv("PPLHIP_GEMM_MAP")) : -1;
         int map_mode = (m_tiles % 8 == 0) ? 1 : 0;
         if (forced == 0) map_mode = 0;
@@ -729,7 +788,9 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
             if (forced_split > 0) splits = forced_split;
             while (splits > 1 && (size_t)splits * M * N * sizeof(float) > ws_bytes) --splits;
         }
+        if (wq_bit == 4 && splits < (kt_all + 2 * W4_MAXG - 1) / (2 * W4_MAXG)) splits = (kt_all + 2 * W4_MAXG - 1) / (2 * W4_MAXG);
         int kt_per = (kt_all + splits - 1) / splits;
+        if (wq_bit == 4) kt_per = (kt_per + 1) & ~1;  // whole quantisation groups per split
         splits = (kt_all + kt_per - 1) / kt_per;  // no empty split
         if (splits > 1) stages = 2;
         g2.y = splits;
@@ -739,7 +800,7 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
 #define DMA_STAGES(WQ, O32)                                                                                         \
     do { if (stages == 2) DMA_LAUNCH(WQ, O32, 2); else if (stages == 3) DMA_LAUNCH(WQ, O32, 3); else DMA_LAUNCH(WQ, O32, 4); } while (0)
 #define DMA_EPI(WQ) do { if (epi == EPI_F32) DMA_STAGES(WQ, EPI_F32); else if (epi == EPI_F16) DMA_STAGES(WQ, EPI_F16); else DMA_STAGES(WQ, EPI_SWIGLU); } while (0)
-        if (wq_bit == 8) DMA_EPI(8); else DMA_EPI(0);
+        if (wq_bit == 8) DMA_EPI(8); else if (wq_bit == 4) DMA_EPI(4); else DMA_EPI(0);
 #undef DMA_EPI
 #undef DMA_STAGES
 #undef DMA_LAUNCH

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times pplhip_op_linear on the four linear shapes of a LLaMA-2-7B layer at M = 1024 (W8A16) with HIP events.
-usage: python profiles/gemm_microbench.py [M]"""
+usage: python profiles/gemm_microbench.py [M] [wq 8|4|0] [7b|7b-tp8|13b-tp2|70b-tp8]"""
 import os, sys
 import numpy as np
 import torch
@@ -8,14 +8,29 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.conftest import load_pplhip
 m = load_pplhip()
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-shapes = [("wqkv", 12288, 4096), ("wo", 4096, 4096), ("w13", 22016, 4096), ("w2", 4096, 11008)]
+WQ = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+MODEL = sys.argv[3] if len(sys.argv) > 3 else "7b"
+SHAPES = {
+    "7b": [("wqkv", 12288, 4096), ("wo", 4096, 4096), ("w13", 22016, 4096), ("w2", 4096, 11008)],
+    "7b-tp8": [("wqkv", 1536, 4096), ("wo", 4096, 512), ("w13", 2752, 4096), ("w2", 4096, 1408)],
+    "13b-tp2": [("wqkv", 7680, 5120), ("wo", 5120, 2560), ("w13", 13824, 5120), ("w2", 5120, 6912)],
+    "70b-tp8": [("wqkv", 1280, 8192), ("wo", 8192, 1024), ("w13", 7168, 8192), ("w2", 8192, 3584)],
+}
+shapes = SHAPES[MODEL]
 tot_t = tot_f = 0
 for name, N, K in shapes:
     x = (torch.randn(M, K, device="cuda") * 0.5).half()
-    w = torch.randint(-127, 128, (N, K), device="cuda", dtype=torch.int8)
-    sc = (torch.rand(N, device="cuda") * 0.001 + 0.0005).half()
+    if WQ == 8:
+        w = torch.randint(-127, 128, (N, K), device="cuda", dtype=torch.int8)
+        sc = (torch.rand(N, device="cuda") * 0.001 + 0.0005).half()
+    elif WQ == 4:
+        w = torch.randint(0, 256, (N, K // 2), device="cuda", dtype=torch.uint8)
+        sc = (torch.rand(N, K // 128, device="cuda") * 0.01 + 0.005).half()
+    else:
+        w = (torch.randn(N, K, device="cuda") * 0.02).half()
+        sc = torch.zeros(1, device="cuda").half()
     y = torch.empty(M, N, device="cuda", dtype=torch.float16)
-    call = lambda: m.lib().pplhip_op_linear(None, x.data_ptr(), w.data_ptr(), sc.data_ptr(), 8, 128, M, N, K, y.data_ptr(), 0)
+    call = lambda: m.lib().pplhip_op_linear(None, x.data_ptr(), w.data_ptr(), sc.data_ptr(), WQ, 128, M, N, K, y.data_ptr(), 0)
     for _ in range(3): call()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
