@@ -641,9 +641,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const uint16_t* __restric
             } else if constexpr (WQ == 8) {
                 a = cvt_i8x8_f16(make_uint2(w4[ks * 2], w4[ks * 2 + 1]));
             } else {
-                const uint32_t word = w4[ks];  // 8 nibbles, low nibble = even k
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a[e] = (_Float16)((float)((int)((word >> (4 * e)) & 15u) - 8) * wsc);
+                const _Float16 sh = (_Float16)wsc;  // exact: wsc came from an fp16
+                a = cvt_i4x8_f16(w4[ks], h2{sh, sh});  // 8 nibbles, low nibble = even k
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
