@@ -18,6 +18,7 @@
 
 #include <algorithm>
 
+#include <type_traits>
 #include "kernels.h"
 
 namespace pplhip {
@@ -258,15 +259,24 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
 
 constexpr int W4_MAXG = 64;  // W4: quantisation groups (of 128 along K) whose scales one block keeps in LDS
 
-template <int WQ, int EPI, int G_ST>  // WQ = 8: int8 weights + per-channel scale; WQ = 0: fp16; WQ = 4: int4, group 128
-__global__ __launch_bounds__(256) void gemm_dma_kernel(const uint16_t* __restrict__ x, const void* __restrict__ wv,
+// WL = wave layout of the 128x128x64 block tile:
+//   0: 4 waves, 2x2, each 64(n) x 64(m);  1: 4 waves, 4x1, each 32(n) x 128(m) x k64;
+//   2: 8 waves, 4(n) x 2(k): each 32(n) x 128(m) x k32 -- the two k-slices of a K tile run on different waves (two waves
+//      per SIMD from ONE block, so a launch with one block per CU still hides LDS/issue latency), partial sums are
+//      exchanged through LDS once at the end and each slice writes half of the tile.
+// WQ = 8: int8 weights + per-channel scale; WQ = 0: fp16; WQ = 4: int4, group 128
+template <int WQ, int EPI, int G_ST, int WL>
+__global__ __launch_bounds__(WL == 2 ? 512 : 256) void gemm_dma_kernel(const uint16_t* __restrict__ x, const void* __restrict__ wv,
                                                              const uint16_t* __restrict__ scale, int64_t M, int N, int K,
                                                              void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles,
                                                              int map_mode, int kt_per_split, float* __restrict__ ws) {
     // ONE __shared__ object (a second one makes hipcc wait vmcnt(0) before every ds_read of a DMA pipeline)
     constexpr int WB2 = WQ == 8 ? 2 : (WQ == 4 ? 1 : 4);   // half-bytes per weight element
     constexpr int W_STAGE = G_BN * G_BK * WB2 / 2;         // 8 KiB (int8) / 16 KiB (fp16) / 4 KiB (int4)
-    constexpr int W_DMA = W_STAGE / 4096;                  // DMA instructions per wave per tile for W
+    constexpr int NT = WL == 2 ? 512 : 256;                // threads
+    constexpr int X_DMA = G_BM * G_BK * 2 / (NT * 16);     // DMA instructions per wave per tile for X (4 or 2)
+    constexpr int W_DMA = W_STAGE / (NT * 16) > 0 ? W_STAGE / (NT * 16) : 1;  // ... for W (int4 at 512 threads: the second
+                                                                              // half of the block re-loads the same 4 KiB)
     constexpr int SC_BYTES = WQ == 4 ? W4_MAXG * G_BN * 2 : 0;  // W4: group scales of this block's rows, [group][row]
     __shared__ __attribute__((aligned(16))) char smem[G_ST * (G_BM * G_BK * 2 + W_STAGE) + SC_BYTES];  // per stage: X 16 KiB + W
     uint16_t* const Xs0 = reinterpret_cast<uint16_t*>(smem);
@@ -280,7 +290,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const uint16_t* __restric
     const int id = blockIdx.x;
     const int xcd = id & 7, slot = id >> 3;
     int nt, mt;
-    if (map_mode == 1) {
+    if ((map_mode & 0xff) == 1) {
         const int mg = m_tiles >> 3;
         mt = xcd + 8 * (slot % mg);
         nt = slot / mg;
@@ -294,16 +304,21 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const uint16_t* __restric
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
-    const int wn = wave >> 1, wm = wave & 1;
+    // WL 1: every wave owns 32 weight rows and all 128 activation rows of the tile, so each weight fragment is converted
+    // (int8/int4 -> fp16) by exactly one wave and feeds 8 MFMAs; WL 0 converts every fragment in two waves for 4 MFMAs
+    constexpr int NI = WL ? 2 : 4, NJ = WL ? 8 : 4;
+    const int wn = WL == 2 ? (wave & 3) : (WL ? wave : wave >> 1), wm = WL ? 0 : wave & 1;
+    const int kg = WL == 2 ? wave >> 2 : 0;  // k-slice of this wave (WL 2)
+    const int nb = wn * (NI * 16), mb = wm * (NJ * 16);  // row bases of this wave inside the tile
 
     // per-lane DMA sources (constant over K except for the k0 term)
-    const uint16_t* xsrc[4];
+    const uint16_t* xsrc[X_DMA];
     const char* wsrc[W_DMA];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < X_DMA; ++j) {
         // LDS position pos = ks*4 + kq of a row holds the source chunk kq*2 + ks, i.e. k = kq*16 + ks*8 .. +8: lane
         // (ks, kq) then multiplies exactly the k range that ONE 16-byte read of the int8 weight row (chunk kq) delivers
-        const int p = j * 256 + tid, row = p >> 3, pos = (p & 7) ^ ((row >> 1) & 7);
+        const int p = j * NT + tid, row = p >> 3, pos = (p & 7) ^ ((row >> 1) & 7);
         const int c = ((pos & 3) << 1) | (pos >> 2);
         int64_t m = m0 + row;
         if (m >= M) m = M - 1;  // rows past M are never stored
@@ -311,7 +326,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const uint16_t* __restric
     }
 #pragma unroll
     for (int j = 0; j < W_DMA; ++j) {
-        const int p = j * 256 + tid;
+        const int p = (WQ == 4 && NT == 512) ? (tid & 255) : j * NT + tid;
         if constexpr (WQ == 8) {
             const int row = p >> 2, c = (p & 3) ^ w_swz(row);
             int n = n0 + row;
@@ -334,19 +349,19 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const uint16_t* __restric
     }
     // wave-uniform LDS destinations (byte addresses): piece j of this wave starts at (j * 256 + wave * 64) * 16
     const uint32_t xdst = __builtin_amdgcn_readfirstlane(lds_addr(Xs0) + wave * 1024);
-    const uint32_t wdst = __builtin_amdgcn_readfirstlane(lds_addr(Wq0) + wave * 1024);
+    const uint32_t wdst = __builtin_amdgcn_readfirstlane(lds_addr(Wq0) + ((WQ == 4 && NT == 512) ? (wave & 3) : wave) * 1024);
     auto issue = [&](int stage, int k0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(xsrc[j] + k0, xdst + stage * (G_BM * G_BK * 2) + j * 4096);
+        for (int j = 0; j < X_DMA; ++j) glds16(xsrc[j] + k0, xdst + stage * (G_BM * G_BK * 2) + j * (NT * 16));
 #pragma unroll
-        for (int j = 0; j < W_DMA; ++j) glds16(wsrc[j] + k0 * WB2 / 2, wdst + stage * W_STAGE + j * 4096);
+        for (int j = 0; j < W_DMA; ++j) glds16(wsrc[j] + k0 * WB2 / 2, wdst + stage * W_STAGE + j * (NT * 16));
     };
 
-    f4 acc[4][4];
+    f4 acc[NI][NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
     // G_ST-stage ring, prefetch distance D = G_ST - 1: while tile t is multiplied, tiles t+1 .. t+D are in flight.  Every
     // wave issues 6 DMA instructions per tile, so "all but the newest 6*j have landed" (vmcnt(6*j)) == tile t is complete
@@ -361,7 +376,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const uint16_t* __restric
         // group scales of this block's 128 rows over its K range -> LDS, transposed to [group][row] (one 32-byte run per
         // 16-lane fragment read); kt0 and kt_per_split are even (launcher), so a group never straddles two splits
         const int G = K / 128, g0 = kt0 >> 1, ng = (ktiles + 1) >> 1;
-        for (int e = tid; e < ng * G_BN; e += 256) {
+        for (int e = tid; e < ng * G_BN; e += NT) {
             const int row = e / ng, g = e - row * ng;
             int n = n0 + row;
             if (n >= N) n = N - 1;
@@ -370,103 +385,129 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const uint16_t* __restric
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // before the counted DMA pipeline starts
     }
 #pragma unroll
-    for (int d = 0; d < D; ++d)
+    for (int d = 0; d < D; ++d) {
         if (d < ktiles) issue(d, (kt0 + d) * G_BK);
+    }
     int st = 0, stn = D;  // stage of tile t, stage of tile t+D
-    h2 gsc[4];            // W4: this lane's four row scales of the current group
+    h2 gsc[NI];           // W4: this lane's row scales of the current group
     for (int t = 0; t < ktiles; ++t) {
         const int younger = (ktiles - 1 - t) < (D - 1) ? (ktiles - 1 - t) : (D - 1);
-        if constexpr (WQ == 4) {  // 5 DMA instructions per wave per tile
-            if (younger >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else if (younger == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else if constexpr (WQ == 8) {  // 6 DMA instructions per wave per tile
-            if (younger >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else if (younger == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {                  // 8 per tile
-            if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        {   // every wave issues PT = X_DMA + W_DMA DMA instructions per tile
+            constexpr int PT = X_DMA + W_DMA;
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PT) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PT) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();  // tile t is published; the stage read during iteration t-1 (== stage of tile t+D) is free
-        if (t + D < ktiles) issue(stn, (kt0 + t + D) * G_BK);
+        if (t + D < ktiles && !(map_mode & 0x100)) issue(stn, (kt0 + t + D) * G_BK);  // 0x100: ablation (PPLHIP_GEMM_ABLATE)
         const uint16_t* xs = Xs0 + st * (G_BM * G_BK);
         const char* wq = Wq0 + st * W_STAGE;
         st = st == G_ST - 1 ? 0 : st + 1;
         stn = stn == G_ST - 1 ? 0 : stn + 1;
         // one 16-byte read per weight row delivers the int8 operands of BOTH k-steps of this lane (k = kq*16 .. +16)
-        uint4 wraw[4];
+        uint4 wraw[NI];
         if constexpr (WQ == 8) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = wn * 64 + i * 16 + l15;
-                wraw[i] = *reinterpret_cast<const uint4*>(&wq[row * G_BK + (kq ^ w_swz(row)) * 16]);
+            for (int i = 0; i < NI; ++i) {
+                const int row = nb + i * 16 + l15;
+                if constexpr (WL == 2) {  // only this wave's k-slice: 8 of the 16 bytes
+                    const uint2 v = *reinterpret_cast<const uint2*>(&wq[row * G_BK + (kq ^ w_swz(row)) * 16 + kg * 8]);
+                    wraw[i].x = v.x; wraw[i].y = v.y;
+                } else {
+                    wraw[i] = *reinterpret_cast<const uint4*>(&wq[row * G_BK + (kq ^ w_swz(row)) * 16]);
+                }
             }
         } else if constexpr (WQ == 4) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = wn * 64 + i * 16 + l15;
-                const uint2 v = *reinterpret_cast<const uint2*>(&wq[row * 32 + ((kq ^ (((row >> 3) & 1) << 1)) * 8)]);
-                wraw[i].x = v.x; wraw[i].y = v.y;
+            for (int i = 0; i < NI; ++i) {
+                const int row = nb + i * 16 + l15;
+                if constexpr (WL == 2) {
+                    wraw[i].x = *reinterpret_cast<const uint32_t*>(&wq[row * 32 + ((kq ^ (((row >> 3) & 1) << 1)) * 8) + kg * 4]);
+                } else {
+                    const uint2 v = *reinterpret_cast<const uint2*>(&wq[row * 32 + ((kq ^ (((row >> 3) & 1) << 1)) * 8)]);
+                    wraw[i].x = v.x; wraw[i].y = v.y;
+                }
             }
             if ((t & 1) == 0) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const _Float16 sv = __builtin_bit_cast(_Float16, Sc[(t >> 1) * G_BN + wn * 64 + i * 16 + l15]);
+                for (int i = 0; i < NI; ++i) {
+                    const _Float16 sv = __builtin_bit_cast(_Float16, Sc[(t >> 1) * G_BN + nb + i * 16 + l15]);
                     gsc[i] = h2{sv, sv};
                 }
             }
         }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            h8 a[4], bfr[4];
+        for (int kk = 0; kk < (WL == 2 ? 1 : 2); ++kk) {
+            const int ks = WL == 2 ? kg : kk;
+            h8 a[NI], bfr[NJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 if constexpr (WQ == 8) {
-                    a[i] = cvt_i8x8_f16(ks == 0 ? make_uint2(wraw[i].x, wraw[i].y) : make_uint2(wraw[i].z, wraw[i].w));
+                    a[i] = cvt_i8x8_f16((WL == 2 || ks == 0) ? make_uint2(wraw[i].x, wraw[i].y) : make_uint2(wraw[i].z, wraw[i].w));
                 } else if constexpr (WQ == 4) {
-                    a[i] = cvt_i4x8_f16(ks == 0 ? wraw[i].x : wraw[i].y, gsc[i]);
+                    a[i] = cvt_i4x8_f16((WL == 2 || ks == 0) ? wraw[i].x : wraw[i].y, gsc[i]);
                 } else {
-                    const int row = wn * 64 + i * 16 + l15;
+                    const int row = nb + i * 16 + l15;
                     a[i] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&wq[(row * G_BK + g_swz(row, ks * 4 + kq) * 8) * 2]));
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = wm * 64 + j * 16 + l15;
+            for (int j = 0; j < NJ; ++j) {
+                const int row = mb + j * 16 + l15;
                 bfr[j] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&xs[row * G_BK + g_swz(row, ks * 4 + kq) * 8]));
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], bfr[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], bfr[j], acc[i][j], 0, 0, 0);
         }
     }
 
+    if constexpr (WL == 2) {
+        // exchange of the two k-slices' partial sums: fragment row i goes to the waves of slice i, which then own the
+        // rows nb + i*16 .. +16 of the tile.  32 KiB of the (now idle) stage buffers per pass.
+        float4* xb = reinterpret_cast<float4*>(smem);
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            __syncthreads();
+            if (kg != pass) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    xb[(wn * NJ + j) * 64 + lane] = make_float4(acc[pass][j][0], acc[pass][j][1], acc[pass][j][2], acc[pass][j][3]);
+            }
+            __syncthreads();
+            if (kg == pass) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const float4 o = xb[(wn * NJ + j) * 64 + lane];
+                    acc[pass][j][0] += o.x; acc[pass][j][1] += o.y; acc[pass][j][2] += o.z; acc[pass][j][3] += o.w;
+                }
+            }
+        }
+    }
     if (gridDim.y > 1) {  // fp32 partial slab [split][M][N]
         float* slab = ws + (int64_t)blockIdx.y * M * N;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + wn * 64 + i * 16 + kq * 4;
-            if (n >= N) continue;
+        for (int i = 0; i < NI; ++i) {
+            const int n = n0 + nb + i * 16 + kq * 4;
+            if (n >= N || (WL == 2 && i != kg)) continue;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t m = m0 + wm * 64 + j * 16 + l15;
+            for (int j = 0; j < NJ; ++j) {
+                const int64_t m = m0 + mb + j * 16 + l15;
                 if (m < M) *reinterpret_cast<float4*>(slab + m * N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
             }
         }
         return;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wn * 64 + i * 16 + kq * 4;
-        if (n >= N) continue;
+    for (int i = 0; i < NI; ++i) {
+        const int n = n0 + nb + i * 16 + kq * 4;
+        if (n >= N || (WL == 2 && i != kg)) continue;
         h4 sh = {(_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f};
         if constexpr (WQ == 8) sh = __builtin_bit_cast(h4, *reinterpret_cast<const uint2*>(scale + n));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t m = m0 + wm * 64 + j * 16 + l15;
+        for (int j = 0; j < NJ; ++j) {
+            const int64_t m = m0 + mb + j * 16 + l15;
             if (m >= M) continue;
             store4<EPI>(yv, ldy, m, n, acc[i][j][0] * (float)sh[0], acc[i][j][1] * (float)sh[1], acc[i][j][2] * (float)sh[2],
                         acc[i][j][3] * (float)sh[3]);
@@ -766,9 +807,12 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
                          (K / 128 <= W4_MAXG || (ws && (size_t)((K / 128 + W4_MAXG - 1) / W4_MAXG) * M * N * sizeof(float) <= ws_bytes));
     if ((wq_bit == 8 || wq_bit == 0 || w4_fast) && K % G_BK == 0 && !getenv("PPLHIP_GEMM_GENERIC")) {
         static const int forced = getenv("PPLHIP_GEMM_MAP") ? atoi(getenv("PPLHIP_GEMM_MAP")) : -1;
-        int map_mode = (m_tiles % 8 == 0) ? 1 : 0;
-        if (forced == 0) map_mode = 0;
+        // measured (profiles/gemm_microbench.py, M = 1024): weight tiles per XCD (mode 0) beats activation slices per XCD
+        // (mode 1) by 2-4 % on every layer shape
+        int map_mode = (forced == 1 && m_tiles % 8 == 0) ? 1 : 0;
         dim3 g2 = map_mode == 1 ? dim3((unsigned)(n_tiles * m_tiles)) : grid;
+        static const int ablate = getenv("PPLHIP_GEMM_ABLATE") ? atoi(getenv("PPLHIP_GEMM_ABLATE")) : 0;  // diagnosis only: wrong results
+        map_mode |= ablate << 8;
         static const int forced_st = getenv("PPLHIP_GEMM_STAGES") ? atoi(getenv("PPLHIP_GEMM_STAGES")) : 0;
         // few blocks per CU -> deeper ring (latency is hidden inside the block); many -> more blocks per CU
         int stages = (int64_t)n_tiles * m_tiles <= 256 ? 4 : 2;  // measured: profiles/gemm_microbench.py
@@ -793,9 +837,13 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         splits = (kt_all + kt_per - 1) / kt_per;  // no empty split
         if (splits > 1) stages = 2;
         g2.y = splits;
+        // wave layout: at most one block per CU (<= 256 tiles) -> 8 waves with the K tile sliced across them (two waves
+        // per SIMD from the one block); more tiles -> 4 waves of 32(n) x 128(m), two blocks per CU
+        static const int forced_wl = getenv("PPLHIP_GEMM_WL") ? atoi(getenv("PPLHIP_GEMM_WL")) : 0;
+        const int wl = forced_wl ? forced_wl : (tiles * splits <= 256 ? 2 : 1);
 #define DMA_LAUNCH(WQ, O32, ST)                                                                                     \
-    hipLaunchKernelGGL((gemm_dma_kernel<WQ, O32, ST>), g2, block, 0, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles, \
-                       map_mode, kt_per, ws)
+    do { if (wl == 2) hipLaunchKernelGGL((gemm_dma_kernel<WQ, O32, ST, 2>), g2, dim3(512), 0, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles, map_mode, kt_per, ws); \
+         else hipLaunchKernelGGL((gemm_dma_kernel<WQ, O32, ST, 1>), g2, block, 0, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles, map_mode, kt_per, ws); } while (0)
 #define DMA_STAGES(WQ, O32)                                                                                         \
     do { if (stages == 2) DMA_LAUNCH(WQ, O32, 2); else if (stages == 3) DMA_LAUNCH(WQ, O32, 3); else DMA_LAUNCH(WQ, O32, 4); } while (0)
 #define DMA_EPI(WQ) do { if (epi == EPI_F32) DMA_STAGES(WQ, EPI_F32); else if (epi == EPI_F16) DMA_STAGES(WQ, EPI_F16); else DMA_STAGES(WQ, EPI_SWIGLU); } while (0)
