@@ -825,9 +825,14 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         const int64_t tiles = (int64_t)n_tiles * m_tiles;
         // (also at larger M when a tensor-parallel slice leaves fewer output tiles than CUs)
         if (ws && ((M <= 256 && tiles < 512) || tiles < 200)) {
-            splits = M <= 256 ? (int)((768 + tiles - 1) / tiles) : (int)((384 + tiles - 1) / tiles);
+            // enough blocks to fill the chip, but every split writes an fp32 slab of the whole output: keep >= min_kt K
+            // tiles per split (measured at M = 64 / 256 on the 70B/TP8 shapes and M = 1024 on 7B/TP8 slices)
+            static const int env_minkt = getenv("PPLHIP_GEMM_MINKT") ? atoi(getenv("PPLHIP_GEMM_MINKT")) : 0;
+            const int target = M <= 64 ? 768 : 512;
+            splits = (int)((target + tiles - 1) / tiles);
             if (splits > 8) splits = 8;
-            if (splits > kt_all / 8) splits = kt_all / 8 > 0 ? kt_all / 8 : 1;  // >= 8 K tiles per split
+            const int min_kt = env_minkt ? env_minkt : ((M <= 64 || tiles < 64) ? 16 : 28);
+            if (splits > kt_all / min_kt) splits = kt_all / min_kt > 0 ? kt_all / min_kt : 1;
             if (forced_split > 0) splits = forced_split;
             while (splits > 1 && (size_t)splits * M * N * sizeof(float) > ws_bytes) --splits;
         }
