@@ -292,3 +292,28 @@ def test_penalty_and_sampling_through_the_abi():
         tok = wtok.astype(np.int64)
         seq = np.arange(n + 1, dtype=np.int64)
     ctx.close()
+
+
+def test_exported_hf_checkpoint_runs_on_the_device(tmp_path_factory):
+    """HF checkpoint -> export_hf_llama.py (W8A16) -> pplhip_rank_load on the device == the oracle on the same containers."""
+    pytest.importorskip("transformers")
+    from tests import test_export_hf as te
+    import json
+    m = load_pplhip()
+    d, prompt, _ = te.make_hf_checkpoint(tmp_path_factory.mktemp("hf"))
+    out = str(tmp_path_factory.mktemp("exported"))
+    te.exp.main(["--model-dir", d, "--out", out, "--quant", "w8a16", "--cache-quant-bit", "8"])
+    want = te.oracle_logits(out, 1, prompt)
+    p = json.load(open(os.path.join(out, "params.json")))
+    desc = m.make_desc(hidden_dim=p["hidden_dim"], intermediate_dim=p["intermediate_dim"], num_layers=p["num_layers"],
+                       num_heads=p["num_heads"], num_kv_heads=p["num_kv_heads"], vocab_size=p["vocab_size"], max_position=p["max_position"],
+                       cache_quant_bit=8, cache_quant_group=8, cache_layout=p["cache_layout"], cache_mode=p["cache_mode"], page_size=0,
+                       weight_quant_bit=8, weight_quant_group=p["weight_quant_group"], norm_eps=p["norm_eps"], rope_theta=p["rope_theta"])
+    ctx = m.Context(desc, max_running_batch=4, max_tokens_per_step=32)
+    ctx.load(0, os.path.join(out, "model_slice_0"))
+    ctx.kv_alloc(0, 64)
+    ctx.set_inputs(0, m.make_step(np.array(prompt), [0, len(prompt)], [0], [0], 0))
+    ctx.run(0)
+    got = ctx.copy_logits(1)[0]
+    assert np.abs(got - want).max() <= 8e-3 * max(1.0, np.abs(want).max())
+    ctx.close()
