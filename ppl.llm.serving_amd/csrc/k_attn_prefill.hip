@@ -16,6 +16,7 @@
 //   is applied identically to the V^T reads).
 //   int8 KV is dequantised to fp16 while staging (one fp16 rounding of q*scale; DESIGN.md "numerics").
 // Oracle: ref_attention (oracle/llama_ref.c).
+#include <type_traits>
 #include "kernels.h"
 
 namespace pplhip {
@@ -33,7 +34,8 @@ __device__ __forceinline__ int k_swz(int key) {
 }
 __device__ __forceinline__ int v_swz(int ch) { return ((ch >> 4) & 7) << 2; }
 
-template <int QBIT, int D>
+template <int QBIT, int D, int MODE>  // MODE = cache_mode (0 contiguous slots, 1 paged): a compile-time split keeps the
+                                      // page-table load and its wait out of the contiguous kernel's prefetch pipeline
 __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t* __restrict__ qkv, KvAddr kv,
                                                                   const int64_t* __restrict__ seq_starts,
                                                                   const int64_t* __restrict__ start_pos,
@@ -82,6 +84,7 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
     // waves whose 16 rows lie entirely beyond the sequence still help staging but skip the MFMAs
     const bool wave_active = (q0 + wave * 16) < seqlen;
 
+    const int64_t slot0 = MODE == 0 ? cache_indices[b] : 0;  // contiguous mode: first slot of the request
     const char* kbase = reinterpret_cast<const char*>(kv.cache) + (int64_t)hk * kv.sH * ELT;
     const char* vbase = kbase + kv.sKV * ELT;
     const uint16_t* ksbase = kv.scale + (int64_t)hk * kv.ssH;
@@ -95,13 +98,13 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
 #pragma unroll
         for (int it = 0; it < IPT; ++it) {
             const int item = threadIdx.x + it * PF_THREADS;
-            if (item < NITEMS) {
+            if (NITEMS % PF_THREADS == 0 || item < NITEMS) {  // compile-time true for D = 128: no exec branch around the loads
                 const int c = item % LPT, kp = item / LPT;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     int64_t key = key0 + 2 * kp + e;
                     if (key >= kv_end) key = kv_end - 1;  // masked later (beyond every row's causal horizon)
-                    const int64_t slot = kv_slot(kv, cache_indices, max_pages, b, key);
+                    const int64_t slot = MODE == 0 ? slot0 + key : kv_slot(kv, cache_indices, max_pages, b, key);
                     kraw[it][e] = *reinterpret_cast<const uint4*>(kbase + (slot * kv.sN + c * CH) * ELT);
                     vraw[it][e] = *reinterpret_cast<const uint4*>(vbase + (slot * kv.sN + c * CH) * ELT);
                     if constexpr (QBIT == 8) {
@@ -116,29 +119,23 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
 #pragma unroll
         for (int it = 0; it < IPT; ++it) {
             const int item = threadIdx.x + it * PF_THREADS;
-            if (item < NITEMS) {
+            if (NITEMS % PF_THREADS == 0 || item < NITEMS) {  // compile-time true for D = 128: no exec branch around the loads
                 const int c = item % LPT, kp = item / LPT;
                 const int ch0 = c * CH;
-                float kf[2][CH], vf[2][CH];
+                // the piece as CH/8 groups of 8 fp16, per key of the pair: int8 -> fp16 exactly (v_perm under the exponent),
+                // times the group's fp16 scale in packed fp16 (one rounding of q * scale, as the oracle's dequantisation)
+                h8 kh[2][CH / 8], vh[2][CH / 8];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     if constexpr (QBIT == 8) {
-                        const uint32_t kw[4] = {kraw[it][e].x, kraw[it][e].y, kraw[it][e].z, kraw[it][e].w};
-                        const uint32_t vw[4] = {vraw[it][e].x, vraw[it][e].y, vraw[it][e].z, vraw[it][e].w};
-#pragma unroll
-                        for (int gi = 0; gi < 2; ++gi) {
-                            const float ks_ = h2f((uint16_t)(ksc[it][e] >> (16 * gi)));
-                            const float vs_ = h2f((uint16_t)(vsc[it][e] >> (16 * gi)));
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) {
-                                const int idx = gi * 8 + i;
-                                kf[e][idx] = (float)(int8_t)(kw[idx >> 2] >> (8 * (idx & 3))) * ks_;
-                                vf[e][idx] = (float)(int8_t)(vw[idx >> 2] >> (8 * (idx & 3))) * vs_;
-                            }
-                        }
+                        const h8 k0 = cvt_i8x8_f16(make_uint2(kraw[it][e].x, kraw[it][e].y)), k1 = cvt_i8x8_f16(make_uint2(kraw[it][e].z, kraw[it][e].w));
+                        const h8 v0 = cvt_i8x8_f16(make_uint2(vraw[it][e].x, vraw[it][e].y)), v1 = cvt_i8x8_f16(make_uint2(vraw[it][e].z, vraw[it][e].w));
+                        const h2 ksc2 = __builtin_bit_cast(h2, ksc[it][e]), vsc2 = __builtin_bit_cast(h2, vsc[it][e]);
+                        kh[e][0] = k0 * ksc2[0]; kh[e][1] = k1 * ksc2[1];
+                        vh[e][0] = v0 * vsc2[0]; vh[e][1] = v1 * vsc2[1];
                     } else {
-                        unpack8(kraw[it][e], kf[e]);
-                        unpack8(vraw[it][e], vf[e]);
+                        kh[e][0] = __builtin_bit_cast(h8, kraw[it][e]);
+                        vh[e][0] = __builtin_bit_cast(h8, vraw[it][e]);
                     }
                 }
 #pragma unroll
@@ -147,13 +144,13 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
 #pragma unroll
                     for (int cc = 0; cc < CH / 8; ++cc) {
                         const int chunk = (ch0 / 8 + cc) ^ k_swz<D>(key);
-                        *reinterpret_cast<uint4*>(&Ks[key * D + chunk * 8]) = pack8(&kf[e][cc * 8]);
+                        *reinterpret_cast<uint4*>(&Ks[key * D + chunk * 8]) = __builtin_bit_cast(uint4, kh[e][cc]);
                     }
                 }
 #pragma unroll
                 for (int i = 0; i < CH; ++i) {
                     const int ch = ch0 + i;
-                    const h2 pr = {(_Float16)vf[0][i], (_Float16)vf[1][i]};
+                    const h2 pr = {vh[0][i >> 3][i & 7], vh[1][i >> 3][i & 7]};
                     Vt[ch * PF_VS + (kp ^ v_swz(ch))] = __builtin_bit_cast(uint32_t, pr);
                 }
             }
@@ -267,8 +264,8 @@ hipError_t launch_attn_prefill(hipStream_t s, const uint16_t* qkv, const KvAddr&
     dim3 grid((unsigned)((max_seq_len + PF_BM - 1) / PF_BM), (unsigned)(B - b0), (unsigned)H);
 #define PF_CASE(QB, DD)                                                                                          \
     if (quant_bit == QB && D == DD) {                                                                            \
-        hipLaunchKernelGGL((attn_prefill_kernel<QB, DD>), grid, dim3(PF_THREADS), 0, s, qkv, kv, seq_starts,     \
-                           start_pos, cache_indices, max_pages, b0, H, Hkv, out);                                \
+        if (kv.mode == 0) hipLaunchKernelGGL((attn_prefill_kernel<QB, DD, 0>), grid, dim3(PF_THREADS), 0, s, qkv, kv, seq_starts, start_pos, cache_indices, max_pages, b0, H, Hkv, out); \
+        else hipLaunchKernelGGL((attn_prefill_kernel<QB, DD, 1>), grid, dim3(PF_THREADS), 0, s, qkv, kv, seq_starts, start_pos, cache_indices, max_pages, b0, H, Hkv, out); \
         return hipGetLastError();                                                                                \
     }
     PF_CASE(8, 128) PF_CASE(0, 128) PF_CASE(8, 64) PF_CASE(0, 64) PF_CASE(8, 32) PF_CASE(0, 32)
@@ -284,7 +281,7 @@ hipError_t launch_attn_prefill(hipStream_t s, const uint16_t* qkv, const KvAddr&
 // 128-key tile and each takes its own 16-key sub-tile (S^T = K.Q^T: 4 MFMAs, P.V: D/16 half-filled MFMAs), keeping a
 // private online-softmax state that is merged through LDS at the end.  Every KV byte is read from HBM once.
 // ---------------------------------------------------------------------------------------------------------------
-template <int QBIT, int D>
+template <int QBIT, int D, int MODE>
 __global__ __launch_bounds__(PF_THREADS) void attn_decode_gqa_kernel(const uint16_t* __restrict__ qkv, KvAddr kv,
                                                                      const int64_t* __restrict__ seq_starts,
                                                                      const int64_t* __restrict__ start_pos,
@@ -334,61 +331,58 @@ __global__ __launch_bounds__(PF_THREADS) void attn_decode_gqa_kernel(const uint1
     float m = -1e30f, l = 0.f;
     const float sm_scale = 1.0f / sqrtf((float)D);
 
+    const int64_t slot0 = MODE == 0 ? cache_indices[b] : 0;  // contiguous mode: first slot of the request
     const char* kbase = reinterpret_cast<const char*>(kv.cache) + (int64_t)hk * kv.sH * ELT;
     const char* vbase = kbase + kv.sKV * ELT;
     const uint16_t* ksbase = kv.scale + (int64_t)hk * kv.ssH;
     const uint16_t* vsbase = ksbase + kv.ssKV;
 
-    uint4 kraw[IPT][2], vraw[IPT][2];
-    uint32_t ksc[IPT][2], vsc[IPT][2];
-    auto load_tile = [&](int64_t key0) {
+    // TWO tiles in flight (register double buffer): a block streams one KV head of one request, so the bytes it keeps
+    // outstanding set its share of the HBM bandwidth
+    uint4 kraw[2][IPT][2], vraw[2][IPT][2];
+    uint32_t ksc[2][IPT][2], vsc[2][IPT][2];
+    auto load_tile = [&](int p, int64_t key0) {
 #pragma unroll
         for (int it = 0; it < IPT; ++it) {
             const int item = threadIdx.x + it * PF_THREADS;
-            if (item < NITEMS) {
+            if (NITEMS % PF_THREADS == 0 || item < NITEMS) {  // compile-time true for D = 128: no exec branch around the loads
                 const int c = item % LPT, kp = item / LPT;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     int64_t key = key0 + 2 * kp + e;
                     if (key >= tend) key = tend - 1;
-                    const int64_t slot = kv_slot(kv, cache_indices, max_pages, b, key);
-                    kraw[it][e] = *reinterpret_cast<const uint4*>(kbase + (slot * kv.sN + c * CH) * ELT);
-                    vraw[it][e] = *reinterpret_cast<const uint4*>(vbase + (slot * kv.sN + c * CH) * ELT);
+                    const int64_t slot = MODE == 0 ? slot0 + key : kv_slot(kv, cache_indices, max_pages, b, key);
+                    kraw[p][it][e] = *reinterpret_cast<const uint4*>(kbase + (slot * kv.sN + c * CH) * ELT);
+                    vraw[p][it][e] = *reinterpret_cast<const uint4*>(vbase + (slot * kv.sN + c * CH) * ELT);
                     if constexpr (QBIT == 8) {
-                        ksc[it][e] = *reinterpret_cast<const uint32_t*>(ksbase + slot * kv.ssN + c * 2);
-                        vsc[it][e] = *reinterpret_cast<const uint32_t*>(vsbase + slot * kv.ssN + c * 2);
+                        ksc[p][it][e] = *reinterpret_cast<const uint32_t*>(ksbase + slot * kv.ssN + c * 2);
+                        vsc[p][it][e] = *reinterpret_cast<const uint32_t*>(vsbase + slot * kv.ssN + c * 2);
                     }
                 }
             }
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int p) {
 #pragma unroll
         for (int it = 0; it < IPT; ++it) {
             const int item = threadIdx.x + it * PF_THREADS;
-            if (item < NITEMS) {
+            if (NITEMS % PF_THREADS == 0 || item < NITEMS) {  // compile-time true for D = 128: no exec branch around the loads
                 const int c = item % LPT, kp = item / LPT;
                 const int ch0 = c * CH;
-                float kf[2][CH], vf[2][CH];
+                // the piece as CH/8 groups of 8 fp16, per key of the pair: int8 -> fp16 exactly (v_perm under the exponent),
+                // times the group's fp16 scale in packed fp16 (one rounding of q * scale, as the oracle's dequantisation)
+                h8 kh[2][CH / 8], vh[2][CH / 8];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     if constexpr (QBIT == 8) {
-                        const uint32_t kw[4] = {kraw[it][e].x, kraw[it][e].y, kraw[it][e].z, kraw[it][e].w};
-                        const uint32_t vw[4] = {vraw[it][e].x, vraw[it][e].y, vraw[it][e].z, vraw[it][e].w};
-#pragma unroll
-                        for (int gi = 0; gi < 2; ++gi) {
-                            const float ks_ = h2f((uint16_t)(ksc[it][e] >> (16 * gi)));
-                            const float vs_ = h2f((uint16_t)(vsc[it][e] >> (16 * gi)));
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) {
-                                const int idx = gi * 8 + i;
-                                kf[e][idx] = (float)(int8_t)(kw[idx >> 2] >> (8 * (idx & 3))) * ks_;
-                                vf[e][idx] = (float)(int8_t)(vw[idx >> 2] >> (8 * (idx & 3))) * vs_;
-                            }
-                        }
+                        const h8 k0 = cvt_i8x8_f16(make_uint2(kraw[p][it][e].x, kraw[p][it][e].y)), k1 = cvt_i8x8_f16(make_uint2(kraw[p][it][e].z, kraw[p][it][e].w));
+                        const h8 v0 = cvt_i8x8_f16(make_uint2(vraw[p][it][e].x, vraw[p][it][e].y)), v1 = cvt_i8x8_f16(make_uint2(vraw[p][it][e].z, vraw[p][it][e].w));
+                        const h2 ksc2 = __builtin_bit_cast(h2, ksc[p][it][e]), vsc2 = __builtin_bit_cast(h2, vsc[p][it][e]);
+                        kh[e][0] = k0 * ksc2[0]; kh[e][1] = k1 * ksc2[1];
+                        vh[e][0] = v0 * vsc2[0]; vh[e][1] = v1 * vsc2[1];
                     } else {
-                        unpack8(kraw[it][e], kf[e]);
-                        unpack8(vraw[it][e], vf[e]);
+                        kh[e][0] = __builtin_bit_cast(h8, kraw[p][it][e]);
+                        vh[e][0] = __builtin_bit_cast(h8, vraw[p][it][e]);
                     }
                 }
 #pragma unroll
@@ -397,24 +391,33 @@ __global__ __launch_bounds__(PF_THREADS) void attn_decode_gqa_kernel(const uint1
 #pragma unroll
                     for (int cc = 0; cc < CH / 8; ++cc) {
                         const int chunk = (ch0 / 8 + cc) ^ k_swz<D>(key);
-                        *reinterpret_cast<uint4*>(&Ks[key * D + chunk * 8]) = pack8(&kf[e][cc * 8]);
+                        *reinterpret_cast<uint4*>(&Ks[key * D + chunk * 8]) = __builtin_bit_cast(uint4, kh[e][cc]);
                     }
                 }
 #pragma unroll
                 for (int i = 0; i < CH; ++i) {
                     const int ch = ch0 + i;
-                    const h2 pr = {(_Float16)vf[0][i], (_Float16)vf[1][i]};
+                    const h2 pr = {vh[0][i >> 3][i & 7], vh[1][i >> 3][i & 7]};
                     Vt[ch * PF_VS + (kp ^ v_swz(ch))] = __builtin_bit_cast(uint32_t, pr);
                 }
             }
         }
     };
 
-    if (tbeg < tend) load_tile(tbeg);
-    for (int64_t key0 = tbeg; key0 < tend; key0 += PF_BN) {
-        store_tile();
+    // the prefetches are unconditional (keys past the range are clamped inside load_tile and re-read the last row):
+    // with a static number of loads per iteration hipcc can wait for exactly the older tile (vmcnt(8..15)); a guarded
+    // prefetch makes it drain both
+    if (tbeg < tend) {
+        load_tile(0, tbeg);
+        load_tile(1, tbeg + PF_BN);
+    }
+    // one tile: buffer P -> LDS, refill buffer P with tile t+2, multiply.  The loop below alternates P = 0, 1 in straight-
+    // line code, so the age of each register buffer is static at every wait.
+    auto tile_step = [&](auto ptag, int64_t key0) {
+        constexpr int P = decltype(ptag)::value;
+        store_tile(P);
         __syncthreads();
-        if (key0 + PF_BN < tend) load_tile(key0 + PF_BN);
+        load_tile(P, key0 + 2 * PF_BN);
         const int64_t kbase_w = key0 + wave * 16;  // this wave's 16-key sub-tile
         if (kbase_w < tend) {
             f4 sacc = f4{0.f, 0.f, 0.f, 0.f};
@@ -470,6 +473,11 @@ __global__ __launch_bounds__(PF_THREADS) void attn_decode_gqa_kernel(const uint1
             }
         }
         __syncthreads();
+    };
+    for (int64_t key0 = tbeg; key0 < tend; key0 += 2 * PF_BN) {
+        tile_step(std::integral_constant<int, 0>{}, key0);
+        if (key0 + PF_BN >= tend) break;
+        tile_step(std::integral_constant<int, 1>{}, key0 + PF_BN);
     }
     // ---- merge the 8 waves: partial (o[head][d], m[head], l[head]) per wave through LDS ------------------------
     float* mg = reinterpret_cast<float*>(smem);  // [wave][16 heads][D + 2]
@@ -520,8 +528,8 @@ hipError_t launch_attn_decode_gqa(hipStream_t s, const uint16_t* qkv, const KvAd
     dim3 grid((unsigned)Hkv, (unsigned)nb, (unsigned)split);
 #define GQ_CASE(QB, DD)                                                                                           \
     if (quant_bit == QB && D == DD) {                                                                             \
-        hipLaunchKernelGGL((attn_decode_gqa_kernel<QB, DD>), grid, dim3(PF_THREADS), 0, s, qkv, kv, seq_starts,   \
-                           start_pos, cache_indices, max_pages, H, Hkv, split, workspace, out);                   \
+        if (kv.mode == 0) hipLaunchKernelGGL((attn_decode_gqa_kernel<QB, DD, 0>), grid, dim3(PF_THREADS), 0, s, qkv, kv, seq_starts, start_pos, cache_indices, max_pages, H, Hkv, split, workspace, out); \
+        else hipLaunchKernelGGL((attn_decode_gqa_kernel<QB, DD, 1>), grid, dim3(PF_THREADS), 0, s, qkv, kv, seq_starts, start_pos, cache_indices, max_pages, H, Hkv, split, workspace, out); \
         return hipGetLastError();                                                                                 \
     }
     GQ_CASE(8, 128) GQ_CASE(0, 128) GQ_CASE(8, 64) GQ_CASE(0, 64) GQ_CASE(8, 32) GQ_CASE(0, 32)

@@ -29,6 +29,18 @@ __device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uin
 __device__ __forceinline__ float round_h(float f) { return (float)(_Float16)f; }
 
 // 16-byte vector of 8 halfs <-> floats
+// 8 int8 -> 8 fp16, exact: x ^ 0x80 is the biased byte u = x + 128; v_perm puts it under the fp16 exponent 0x64
+// (= 1024 + u), minus 1152 gives x.  Two VALU ops per pair.
+__device__ __forceinline__ h8 cvt_i8x8_f16(uint2 v) {
+    const uint32_t w0 = v.x ^ 0x80808080u, w1 = v.y ^ 0x80808080u;
+    const h2 bias = {(_Float16)1152.0f, (_Float16)1152.0f};
+    const h2 a = __builtin_bit_cast(h2, __builtin_amdgcn_perm(0x64646464u, w0, 0x04010400u)) - bias;
+    const h2 b = __builtin_bit_cast(h2, __builtin_amdgcn_perm(0x64646464u, w0, 0x04030402u)) - bias;
+    const h2 c = __builtin_bit_cast(h2, __builtin_amdgcn_perm(0x64646464u, w1, 0x04010400u)) - bias;
+    const h2 d = __builtin_bit_cast(h2, __builtin_amdgcn_perm(0x64646464u, w1, 0x04030402u)) - bias;
+    return h8{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+}
+
 __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
     const h8 h = __builtin_bit_cast(h8, v);
 #pragma unroll
