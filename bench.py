@@ -156,6 +156,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tpb", type=int, default=0)
     ap.add_argument("--prefill-sample", type=int, default=1, help="also time one 8192-token prefill step (TTFT proxy)")
+    ap.add_argument("--cache-mode", type=int, default=0, choices=[0, 1],
+                    help="0: contiguous KV ranges (default, as the metric is quoted), 1: paged KV with shuffled 16-token pages")
     ap.add_argument("--emulate-tp", type=int, default=0,
                     help="profiling only: run ONE rank's slice of a tp-way step on one GPU (collectives are local "
                          "identities, logits incomplete); the printed line is marked invalid as a throughput number")
@@ -186,7 +188,8 @@ def main():
     B, K, W = args.batch, args.steps, args.warmup
     total_len = args.kv_len + K + W + 2
     desc = P.make_desc(max_position=max(2048, total_len + 1), cache_quant_bit=args.kv_quant,
-                       cache_quant_group=8 if args.kv_quant else 1, cache_layout=3, cache_mode=0,
+                       cache_quant_group=8 if args.kv_quant else 1, cache_layout=3, cache_mode=args.cache_mode,
+                       page_size=16 if args.cache_mode else 0,
                        weight_quant_bit=args.weight_quant, **mk)
     uid = None
     if world > 1:
@@ -201,7 +204,7 @@ def main():
     ctx = P.Context(desc, max_running_batch=B, max_tokens_per_step=max(8192, B), n_local_ranks=1, world_size=tp,
                     rank_base=rank, device_ids=[local_rank], unique_id=uid, profiling=True, tpb=args.tpb)
     ctx.init_synthetic(0, 1234)
-    kv_tokens = B * total_len
+    kv_tokens = B * total_len if args.cache_mode == 0 else B * ((total_len + 15) // 16) * 16
     cap = ctx.kv_capacity(0.94)
     if kv_tokens > cap:
         sys.exit(f"KV slab needs {kv_tokens} tokens but only {cap} fit")
@@ -211,6 +214,12 @@ def main():
 
     rng = np.random.RandomState(1234)
     cache_idx = (np.arange(B, dtype=np.int64) * total_len)
+    max_pages = 0
+    if args.cache_mode == 1:  # every request owns ceil(total_len / 16) pages drawn from a shuffled pool
+        max_pages = (total_len + 15) // 16
+        kv_need = B * max_pages * 16
+        pool = np.random.RandomState(7).permutation(kv_need // 16).astype(np.int64)
+        cache_idx = pool[:B * max_pages].reshape(B, max_pages)
     seq_starts = np.arange(B + 1, dtype=np.int64)
     tok = rng.randint(3, desc.vocab_size, size=B).astype(np.int64)
 
@@ -220,7 +229,7 @@ def main():
             dist.barrier()
 
     def step(i, tok):
-        st = P.make_step(tok, seq_starts, np.full(B, args.kv_len + i, dtype=np.int64), cache_idx, B,
+        st = P.make_step(tok, seq_starts, np.full(B, args.kv_len + i, dtype=np.int64), cache_idx, B, max_pages=max_pages,
                          req_list_changed=1 if i == 0 else 0)
         ctx.set_inputs(0, st)
         ctx.run(0)
@@ -264,8 +273,12 @@ def main():
         nreq, plen = 16, 512
         if nreq * plen <= kv_tokens:
             ptok = rng.randint(3, desc.vocab_size, size=nreq * plen).astype(np.int64)
-            st = P.make_step(ptok, np.arange(nreq + 1) * plen, np.zeros(nreq, dtype=np.int64),
-                             (np.arange(nreq, dtype=np.int64) * total_len), 0)
+            if args.cache_mode == 0:
+                pci, pmp = (np.arange(nreq, dtype=np.int64) * total_len), 0
+            else:
+                pmp = (plen + 15) // 16
+                pci = cache_idx[:nreq, :pmp] if max_pages >= pmp else None
+            st = P.make_step(ptok, np.arange(nreq + 1) * plen, np.zeros(nreq, dtype=np.int64), pci, 0, max_pages=pmp)
             for rep in range(2):
                 barrier()
                 t1 = time.perf_counter()
@@ -285,7 +298,7 @@ def main():
             "vs_baseline": None, "dtype": "fp16 activations, int8 weights (W8A16), int8-g8 KV, fp32 accumulate",
             "data": "synthetic (device-generated weights and KV history, random token ids)",
             "config": {"workload": f"{args.model} W{args.weight_quant or 16}A16 decode, batch {B}, kv_len {args.kv_len}"
-                                   f"..{args.kv_len + K + W}, greedy top_k=1, cache_layout 3 / cache_mode 0, "
+                                   f"..{args.kv_len + K + W}, greedy top_k=1, cache_layout 3 / cache_mode {args.cache_mode}, "
                                    f"kv int{args.kv_quant or 16}", "global_batch": B, "seq_len": 1024,
                        "parallelism": f"tp{world}", "layers": desc.num_layers},
             "roofline": {"kernel": "attn_decode_kernel<8,128>" if args.kv_quant else "attn_decode_kernel<0,128>",
