@@ -65,7 +65,13 @@ int main(int argc, char** argv) {
         conn.Wait();
         const auto t1 = tools::Clock::now();
         std::vector<double> v;
-        for (auto& r : reqs) v.push_back(tools::Ms(conn.records()[r->id].submit, conn.records()[r->id].first));
+        for (auto& r : reqs) {
+            if (conn.records()[r->id].failed) {  // e.g. prompt longer than --max-input-tokens-per-request
+                std::cerr << "run " << run << ": request " << r->id << " was rejected; no timing reported\n";
+                return 1;
+            }
+            v.push_back(tools::Ms(conn.records()[r->id].submit, conn.records()[r->id].first));
+        }
         ttft[run] = tools::Percentile(v, 50);
         total[run] = tools::Ms(t0, t1);
         while (!generator->IsIdle()) std::this_thread::sleep_for(std::chrono::milliseconds(1));
