@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Decode step latency at small batch (7B W8A16, int8 KV, kv_len 512) without the profiling events of bench.py.
+usage: python profiles/small_batch_latency.py [batch ...]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.conftest import load_pplhip
+P = load_pplhip()
+MK = dict(hidden_dim=4096, intermediate_dim=11008, num_layers=32, num_heads=32, num_kv_heads=32, vocab_size=32000)
+KV, STEPS, WARM = 512, 64, 8
+batches = [int(a) for a in sys.argv[1:]] or [1, 4, 16]
+desc = P.make_desc(max_position=2048, cache_quant_bit=8, cache_quant_group=8, cache_layout=3, cache_mode=0, weight_quant_bit=8, **MK)
+ctx = P.Context(desc, max_running_batch=max(batches), max_tokens_per_step=max(max(batches), 64), profiling=False)
+ctx.init_synthetic(0, 1234)
+tl = KV + STEPS + WARM + 2
+ctx.kv_alloc(0, max(batches) * tl); ctx.kv_fill_synthetic(0, 9)
+for B in batches:
+    tok = np.random.RandomState(0).randint(3, 32000, size=B).astype(np.int64)
+    ci = np.arange(B, dtype=np.int64) * tl
+    seq = np.arange(B + 1)
+    def step(i, tok):
+        ctx.set_inputs(0, P.make_step(tok, seq, np.full(B, KV + i), ci, B, req_list_changed=int(i == 0)))
+        ctx.run(0)
+        return ctx.sample(B, top_k=1, req_list_changed=(i == 0))[0].astype(np.int64)
+    for i in range(WARM): tok = step(i, tok)
+    ctx.sync(0); t0 = time.perf_counter()
+    for i in range(WARM, WARM + STEPS): tok = step(i, tok)
+    ctx.sync(0); dt = (time.perf_counter() - t0) / STEPS
+    print(f"batch {B}: {dt*1e3:.3f} ms/step = {B/dt:.1f} tokens/s")
