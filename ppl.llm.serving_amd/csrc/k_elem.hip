@@ -49,6 +49,13 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint4* x /* may alia
             for (int j = 0; j < 8; ++j) ss += v[i][j] * v[i][j];
         }
     }
+    // the norm weights are fetched before the reduction so that their latency hides under it
+    uint4 wraw[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = threadIdx.x + i * 256;
+        wraw[i] = c < chunks ? w[c] : make_uint4(0, 0, 0, 0);
+    }
     ss = wave_sum(ss);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
     __syncthreads();
@@ -59,7 +66,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint4* x /* may alia
         const int c = threadIdx.x + i * 256;
         if (c < chunks) {
             float wf[8], o[8];
-            unpack8(w[c], wf);
+            unpack8(wraw[i], wf);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = v[i][j] * inv * wf[j];
             out[r * chunks + c] = pack8(o);

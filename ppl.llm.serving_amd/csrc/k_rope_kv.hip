@@ -47,10 +47,17 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(uint16_t* __restrict
     __shared__ int64_t sh_b;
     const int64_t t = t0 + blockIdx.x;
     if (threadIdx.x == 0) {  // request of row t: last b with seq_starts[b] <= t
+        // decode rows come first and have one token each, so row t usually IS request t: two independent loads instead
+        // of a chain of log2(B) dependent ones in front of every block
+        const int64_t g = t < B ? t : B - 1;
         int64_t lo = 0, hi = B - 1;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi + 1) >> 1;
-            if (seq_starts[mid] <= t) lo = mid; else hi = mid - 1;
+        if (seq_starts[g] <= t && t < seq_starts[g + 1]) {
+            lo = g;
+        } else {
+            while (lo < hi) {
+                const int64_t mid = (lo + hi + 1) >> 1;
+                if (seq_starts[mid] <= t) lo = mid; else hi = mid - 1;
+            }
         }
         sh_b = lo;
     }
