@@ -685,8 +685,42 @@ int pplhip_set_inputs(pplhip_ctx* c, int rank, const pplhip_step* st) {
     const int64_t B = st->batch, T = st->num_tokens;
     if (B < 0 || T < 0 || B > R.cap_B || T > R.cap_T)
         return fail(c, rank, PPLHIP_INVALID_VALUE, "step exceeds max_running_batch / max_tokens_per_step");
-    if (B > 0 && (!st->token_inputs || !st->seq_starts || !st->kv_starts || !st->start_pos)) return PPLHIP_INVALID_VALUE;
+    if (B == 0) {  // an empty step is legal (LLMGenerator never sends one, llm_generator.cc:658-660) and does nothing
+        if (T != 0) return fail(c, rank, PPLHIP_INVALID_VALUE, "tokens without requests");
+        R.B = 0; R.T = 0; R.decoding_batches = 0; R.h_seq = nullptr;
+        return 0;
+    }
+    if (!st->token_inputs || !st->seq_starts || !st->kv_starts || !st->start_pos) return PPLHIP_INVALID_VALUE;
     if (st->max_kv_len > c->d.max_position) return fail(c, rank, PPLHIP_INVALID_VALUE, "max_kv_len exceeds max_position");
+    {   // the kernels index the rope table, the embedding table and the KV slab with these values: reject anything that
+        // would leave them (O(B + T) on the host; the reference trusts its generator, this boundary does not)
+        const int64_t* ss = st->seq_starts;
+        if (ss[0] != 0 || ss[B] != T) return fail(c, rank, PPLHIP_INVALID_VALUE, "seq_starts must run from 0 to num_tokens");
+        if (st->decoding_batches < 0 || st->decoding_batches > B) return fail(c, rank, PPLHIP_INVALID_VALUE, "decoding_batches out of range");
+        const int64_t P = c->d.page_size > 0 ? c->d.page_size : 1;
+        for (int64_t b = 0; b < B; ++b) {
+            const int64_t len = ss[b + 1] - ss[b], sp = st->start_pos[b];
+            if (len <= 0) return fail(c, rank, PPLHIP_INVALID_VALUE, "request " + std::to_string(b) + " has no tokens");
+            if (b < st->decoding_batches && len != 1) return fail(c, rank, PPLHIP_INVALID_VALUE, "decode request " + std::to_string(b) + " must have one token");
+            if (sp < 0 || sp + len > c->d.max_position) return fail(c, rank, PPLHIP_INVALID_VALUE, "request " + std::to_string(b) + " exceeds max_position");
+            if (c->d.cache_mode == 0) {
+                const int64_t ci = st->cache_indices ? st->cache_indices[b] : -1;
+                if (ci < 0 || (uint64_t)(ci + sp + len) > R.kv_tokens)
+                    return fail(c, rank, PPLHIP_INVALID_VALUE, "request " + std::to_string(b) + ": KV range outside the slab");
+            } else if (st->req_list_changed && st->cache_indices && st->max_pages > 0) {
+                const int64_t need = (sp + len + P - 1) / P;
+                if (need > st->max_pages) return fail(c, rank, PPLHIP_INVALID_VALUE, "request " + std::to_string(b) + ": page list too short");
+                for (int64_t pg = 0; pg < need; ++pg) {
+                    const int64_t id = st->cache_indices[b * st->max_pages + pg];
+                    if (id < 0 || (uint64_t)id >= R.kv_tokens / (uint64_t)P)  // (also catches the INT64_MAX padding)
+                        return fail(c, rank, PPLHIP_INVALID_VALUE, "request " + std::to_string(b) + ": page outside the slab");
+                }
+            }
+        }
+        for (int64_t t = 0; t < T; ++t)
+            if (st->token_inputs[t] < 0 || st->token_inputs[t] >= c->d.vocab_size)
+                return fail(c, rank, PPLHIP_INVALID_VALUE, "token id outside the vocabulary at row " + std::to_string(t));
+    }
     HIPCK(c, rank, hipSetDevice(R.device));
     const int cur = R.stage_cur;
     R.stage_cur ^= 1;
