@@ -1,0 +1,113 @@
+"""The gRPC front end on the GPU: serving/grpc_server.py (wire format of the reference's llm.proto) in a subprocess, a raw
+grpc client in the test.  Greedy token streams must equal the oracle's continuation; a rejected request answers FAILED; the
+load generator (client_qps_measure_token_in_out.py) runs against the same server."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from oracle import ref
+from tests.conftest import ROOT
+from tests.test_gpu_tools import CFG, PKG, oracle_greedy
+
+pytestmark = pytest.mark.gpu
+grpc = pytest.importorskip("grpc")
+sys.path.insert(0, os.path.join(PKG, "serving"))
+import llm_proto as P  # noqa: E402
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.fixture(scope="module")
+def server():
+    assert os.path.exists(os.path.join(PKG, "build", "libpplserving_c.so")), "run __graft_entry__.build()"
+    port = free_port()
+    proc = subprocess.Popen([sys.executable, os.path.join(PKG, "serving", "grpc_server.py"), "--model-param-path", CFG,
+                             "--synthetic-weights", "--synthetic-seed", "77", "--kv-cache-max-tokens", "2048", "--max-running-batch", "16",
+                             "--max-tokens-per-step", "256", "--max-input-tokens-per-request", "64", "--host", "127.0.0.1",
+                             "--port", str(port)], stderr=subprocess.PIPE, text=True)
+    t0 = time.time()
+    line = ""
+    while time.time() - t0 < 120:
+        line = proc.stderr.readline()
+        if "listening" in line or proc.poll() is not None:
+            break
+    assert "listening" in line, f"server did not start: {line}"
+    yield f"127.0.0.1:{port}"
+    proc.terminate()
+    try:
+        proc.wait(timeout=20)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+
+
+def call(target, reqs):
+    """reqs: list of (id, tokens, max_new_tokens); returns {id: (tokens, statuses, finish_reason)}"""
+    out = {}
+    with grpc.insecure_channel(target) as ch:
+        stub = ch.unary_stream(P.METHOD, request_serializer=P.BatchedRequest.SerializeToString,
+                               response_deserializer=P.BatchedResponse.FromString)
+        br = P.BatchedRequest()
+        for rid, toks, n in reqs:
+            r = br.req.add()
+            r.id = rid
+            r.tokens.ids.extend(toks)
+            r.stopping_parameters.max_new_tokens = n
+            r.stopping_parameters.ignore_eos_token = True
+        for batch in stub(br, timeout=120):
+            for rsp in batch.rsp:
+                rec = out.setdefault(rsp.id, ([], [], []))
+                rec[1].append(rsp.status)
+                if rsp.status != P.FAILED:
+                    rec[0].extend(rsp.tokens.ids)
+                    rec[2].append(rsp.detail.finish_reason)
+    return out
+
+
+def test_streams_equal_the_oracle(server):
+    cfg = json.load(open(CFG))
+    desc = ref.make_desc(hidden_dim=cfg["hidden_dim"], intermediate_dim=cfg["intermediate_dim"], num_layers=cfg["num_layers"],
+                         num_heads=cfg["num_heads"], num_kv_heads=cfg["num_kv_heads"], vocab_size=cfg["vocab_size"],
+                         max_position=cfg["max_position"], cache_quant_bit=8, cache_quant_group=8, cache_layout=3, cache_mode=1,
+                         page_size=4, weight_quant_bit=8)
+    rng = np.random.RandomState(4)
+    reqs = [(100 + i, rng.randint(3, cfg["vocab_size"], size=n).tolist(), g) for i, (n, g) in enumerate([(9, 6), (3, 8), (17, 5)])]
+    got = call(server, reqs)
+    assert sorted(got) == [100, 101, 102]                                   # the client's ids come back
+    compared = 0
+    for rid, toks, g in reqs:
+        tokens, statuses, reasons = got[rid]
+        assert len(tokens) == g and statuses[-1] == P.FINISHED and all(s == P.PROCESSING for s in statuses[:-1])
+        assert reasons[-1] == 0                                             # FINISH_REASON_LENGTH
+        want, margins = oracle_greedy(desc, 77, toks, g)
+        for i, (a, b) in enumerate(zip(tokens, want)):
+            if margins[i] < 8e-3:
+                break
+            assert a == b, (rid, i, tokens, want)
+            compared += 1
+    assert compared >= 8
+
+
+def test_rejected_request_answers_failed_and_others_proceed(server):
+    got = call(server, [(1, list(range(3, 3 + 100)), 4), (2, [5, 6, 7], 3)])    # 100 tokens > --max-input-tokens-per-request 64
+    assert got[1][1] == [P.FAILED] and got[1][0] == []
+    assert len(got[2][0]) == 3 and got[2][1][-1] == P.FINISHED
+
+
+def test_load_generator_against_the_server(server):
+    out = subprocess.check_output([sys.executable, os.path.join(PKG, "serving", "client_qps_measure_token_in_out.py"), "--target", server,
+                                   "--num-requests", "24", "--request-rate", "200", "--vocab-size", "1024", "--max-seq-len", "64"],
+                                  timeout=300).decode()
+    res = json.loads(out.strip().splitlines()[-1])
+    assert res["failed"] == 0 and res["requests"] == 24 and res["out_tps"] > 0 and res["ttft_ms"]["p50"] > 0
