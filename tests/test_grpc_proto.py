@@ -54,3 +54,20 @@ def test_parse_request_defaults():
     pb.choosing_parameters.do_sample = False        # sampling off overrides top_k / top_p
     kw = gs.parse_request(pb)
     assert kw["top_k"] == 1 and kw["top_p"] == 0.0
+
+
+def test_tokenizer_text_path(tmp_path):
+    """sentencepiece text path of the server: BOS first, and a decoded piece gets its leading space back when the piece
+    starts with U+2581 (src/tokenizer/tokenizer_impl_sp.h:53-59)"""
+    spm = pytest.importorskip("sentencepiece")
+    corpus = tmp_path / "corpus.txt"
+    corpus.write_text("\n".join(["the quick brown fox jumps over the lazy dog", "hello world this is a tokenizer test",
+                                 "the president of the united states", "the capital of france is paris"] * 20))
+    spm.SentencePieceTrainer.train(input=str(corpus), model_prefix=str(tmp_path / "tok"), vocab_size=64, model_type="bpe",
+                                   bos_id=1, eos_id=2, unk_id=0, minloglevel=2)
+    tok = gs.Tokenizer(str(tmp_path / "tok.model"))
+    ids = tok.encode("the quick fox")
+    assert ids[0] == 1 and len(ids) > 1
+    text = "".join(tok.decode_one(t) for t in ids[1:])
+    assert text.strip() == "the quick fox"
+    assert text.startswith(" ")          # the first word piece carries the U+2581 marker
