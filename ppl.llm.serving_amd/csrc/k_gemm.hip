@@ -775,7 +775,8 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
     if (wq_bit == 0 && K % 8) return hipErrorInvalidValue;
     if (wq_bit == 8 && K % 16) return hipErrorInvalidValue;
     if (wq_bit == 4 && (K % 32 || group % 32 || K % group)) return hipErrorInvalidValue;
-    if (M <= 16 && !getenv("PPLHIP_GEMM_NOSKINNY")) {  // above 16 rows the split-K tiled kernel is faster (profiles/gemm_microbench.py)
+    static const bool no_skinny = getenv("PPLHIP_GEMM_NOSKINNY") != nullptr, force_generic = getenv("PPLHIP_GEMM_GENERIC") != nullptr;
+    if (M <= 16 && !no_skinny) {  // above 16 rows the split-K tiled kernel is faster (profiles/gemm_microbench.py)
 #define GEMV_DISPATCH(WQ)                                                                                      \
     if (wq_bit == WQ)                                                                                          \
         return epi == EPI_F32 ? launch_gemv<WQ, EPI_F32>(s, x, w, scale, group, M, N, K, y, ldy)               \
@@ -789,7 +790,7 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
     const int n_tiles_pad = (n_tiles + 7) / 8 * 8;
     dim3 grid((unsigned)(n_tiles_pad * m_tiles)), block(256);
     static const int min_m256 = getenv("PPLHIP_GEMM_256_MIN_M") ? atoi(getenv("PPLHIP_GEMM_256_MIN_M")) : 4096;  // measured: only pays at M >= 4096
-    if (wq_bit == 8 && K % G_BK == 0 && M >= min_m256 && N >= 1024 && !getenv("PPLHIP_GEMM_GENERIC")) {
+    if (wq_bit == 8 && K % G_BK == 0 && M >= min_m256 && N >= 1024 && !force_generic) {
         const int nt2 = (N + H_BN - 1) / H_BN, mt2 = (int)((M + H_BM - 1) / H_BM);
         const size_t lds = (size_t)H_ST * (H_BM * G_BK * 2 + H_BN * G_BK);
         dim3 g256((unsigned)((nt2 + 7) / 8 * 8 * mt2));
@@ -808,7 +809,7 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
     // W4: group 128 = two K tiles; one block keeps at most W4_MAXG groups of scales in LDS
     const bool w4_fast = wq_bit == 4 && group == 128 && K % 128 == 0 &&
                          (K / 128 <= W4_MAXG || (ws && (size_t)((K / 128 + W4_MAXG - 1) / W4_MAXG) * M * N * sizeof(float) <= ws_bytes));
-    if ((wq_bit == 8 || wq_bit == 0 || w4_fast) && K % G_BK == 0 && !getenv("PPLHIP_GEMM_GENERIC")) {
+    if ((wq_bit == 8 || wq_bit == 0 || w4_fast) && K % G_BK == 0 && !force_generic) {
         static const int forced = getenv("PPLHIP_GEMM_MAP") ? atoi(getenv("PPLHIP_GEMM_MAP")) : -1;
         // measured (profiles/gemm_microbench.py, M = 1024): weight tiles per XCD (mode 0) beats activation slices per XCD
         // (mode 1) by 2-4 % on every layer shape
