@@ -251,22 +251,19 @@ constexpr int W4_MAXG = 64;  // W4: quantisation groups (of 128 along K) whose s
 
 // WL = wave layout of the 128x128x64 block tile:
 //   0: 4 waves, 2x2, each 64(n) x 64(m);  1: 4 waves, 4x1, each 32(n) x 128(m) x k64;
-//   2: 8 waves, 4(n) x 2(k): each 32(n) x 128(m) x k32 -- the two k-slices of a K tile run on different waves (two waves
-//      per SIMD from ONE block, so a launch with one block per CU still hides LDS/issue latency), partial sums are
-//      exchanged through LDS once at the end and each slice writes half of the tile.
+//   5: 8 waves: 4 consumers with the layout of 1 and 4 producers that do nothing but issue the ring's LDS-DMA;
 // WQ = 8: int8 weights + per-channel scale; WQ = 0: fp16; WQ = 4: int4, group 128
 template <int WQ, int EPI, int G_ST, int WL>
-__global__ __launch_bounds__(WL == 2 ? 512 : 256) void gemm_dma_kernel(const uint16_t* __restrict__ x, const void* __restrict__ wv,
+__global__ __launch_bounds__(WL == 5 ? 512 : 256) void gemm_dma_kernel(const uint16_t* __restrict__ x, const void* __restrict__ wv,
                                                              const uint16_t* __restrict__ scale, int64_t M, int N, int K,
                                                              void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles,
                                                              int map_mode, int kt_per_split, float* __restrict__ ws) {
     // ONE __shared__ object (a second one makes hipcc wait vmcnt(0) before every ds_read of a DMA pipeline)
     constexpr int WB2 = WQ == 8 ? 2 : (WQ == 4 ? 1 : 4);   // half-bytes per weight element
     constexpr int W_STAGE = G_BN * G_BK * WB2 / 2;         // 8 KiB (int8) / 16 KiB (fp16) / 4 KiB (int4)
-    constexpr int NT = WL == 2 ? 512 : 256;                // threads
+    constexpr int NT = 256;                                // threads that move tile pieces (WL 5: the 4 producer waves)
     constexpr int X_DMA = G_BM * G_BK * 2 / (NT * 16);     // DMA instructions per wave per tile for X (4 or 2)
-    constexpr int W_DMA = W_STAGE / (NT * 16) > 0 ? W_STAGE / (NT * 16) : 1;  // ... for W (int4 at 512 threads: the second
-                                                                              // half of the block re-loads the same 4 KiB)
+    constexpr int W_DMA = W_STAGE / (NT * 16);             // ... for W (2 int8, 4 fp16, 1 int4)
     constexpr int SC_BYTES = WQ == 4 ? W4_MAXG * G_BN * 2 : 0;  // W4: group scales of this block's rows, [group][row]
     __shared__ __attribute__((aligned(16))) char smem[G_ST * (G_BM * G_BK * 2 + W_STAGE) + SC_BYTES];  // per stage: X 16 KiB + W
     uint16_t* const Xs0 = reinterpret_cast<uint16_t*>(smem);
@@ -292,13 +289,14 @@ __global__ __launch_bounds__(WL == 2 ? 512 : 256) void gemm_dma_kernel(const uin
     const int n0 = nt * G_BN;
     const int64_t m0 = (int64_t)mt * G_BM;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // WL 5: waves 4..7 only issue the LDS-DMA of the ring (producers), waves 0..3 only multiply (consumers, layout of WL 1)
+    const bool producer = WL == 5 && threadIdx.x >= 256;
+    const int tid = WL == 5 ? (threadIdx.x & 255) : threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
     // WL 1: every wave owns 32 weight rows and all 128 activation rows of the tile, so each weight fragment is converted
     // (int8/int4 -> fp16) by exactly one wave and feeds 8 MFMAs; WL 0 converts every fragment in two waves for 4 MFMAs
     constexpr int NI = WL ? 2 : 4, NJ = WL ? 8 : 4;
-    const int wn = WL == 2 ? (wave & 3) : (WL ? wave : wave >> 1), wm = WL ? 0 : wave & 1;
-    const int kg = WL == 2 ? wave >> 2 : 0;  // k-slice of this wave (WL 2)
+    const int wn = WL ? wave : wave >> 1, wm = WL ? 0 : wave & 1;
     const int nb = wn * (NI * 16), mb = wm * (NJ * 16);  // row bases of this wave inside the tile
 
     // per-lane DMA sources (constant over K except for the k0 term)
@@ -316,7 +314,7 @@ __global__ __launch_bounds__(WL == 2 ? 512 : 256) void gemm_dma_kernel(const uin
     }
 #pragma unroll
     for (int j = 0; j < W_DMA; ++j) {
-        const int p = (WQ == 4 && NT == 512) ? (tid & 255) : j * NT + tid;
+        const int p = j * NT + tid;
         if constexpr (WQ == 8) {
             const int row = p >> 2, c = (p & 3) ^ w_swz(row);
             int n = n0 + row;
@@ -339,7 +337,7 @@ __global__ __launch_bounds__(WL == 2 ? 512 : 256) void gemm_dma_kernel(const uin
     }
     // wave-uniform LDS destinations (byte addresses): piece j of this wave starts at (j * 256 + wave * 64) * 16
     const uint32_t xdst = __builtin_amdgcn_readfirstlane(lds_addr(Xs0) + wave * 1024);
-    const uint32_t wdst = __builtin_amdgcn_readfirstlane(lds_addr(Wq0) + ((WQ == 4 && NT == 512) ? (wave & 3) : wave) * 1024);
+    const uint32_t wdst = __builtin_amdgcn_readfirstlane(lds_addr(Wq0) + wave * 1024);
     auto issue = [&](int stage, int k0) {
 #pragma unroll
         for (int j = 0; j < X_DMA; ++j) glds16(xsrc[j] + k0, xdst + stage * (G_BM * G_BK * 2) + j * (NT * 16));
@@ -376,20 +374,36 @@ __global__ __launch_bounds__(WL == 2 ? 512 : 256) void gemm_dma_kernel(const uin
     }
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        if (d < ktiles) issue(d, (kt0 + d) * G_BK);
+        if (d < ktiles && (WL != 5 || producer)) issue(d, (kt0 + d) * G_BK);
     }
     int st = 0, stn = D;  // stage of tile t, stage of tile t+D
     h2 gsc[NI];           // W4: this lane's row scales of the current group
+    if (WL == 5 && producer) {
+        // producer waves: wait for their own pieces of tile t, meet the consumers at the barrier, refill the freed stage.
+        // The LDS-DMA issue (~100 cycles per piece for the issuing wave) now runs beside the consumers' MFMA stream on
+        // the SIMD instead of in front of it.
+        for (int t = 0; t < ktiles; ++t) {
+            const int younger = (ktiles - 1 - t) < (D - 1) ? (ktiles - 1 - t) : (D - 1);
+            constexpr int PT = X_DMA + W_DMA;
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PT) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t + D < ktiles) issue(stn, (kt0 + t + D) * G_BK);
+            stn = stn == G_ST - 1 ? 0 : stn + 1;
+        }
+        return;
+    }
     for (int t = 0; t < ktiles; ++t) {
         const int younger = (ktiles - 1 - t) < (D - 1) ? (ktiles - 1 - t) : (D - 1);
-        {   // every wave issues PT = X_DMA + W_DMA DMA instructions per tile
+        if constexpr (WL != 5) {   // every wave issues PT = X_DMA + W_DMA DMA instructions per tile
             constexpr int PT = X_DMA + W_DMA;
             if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PT) : "memory");
             else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PT) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();  // tile t is published; the stage read during iteration t-1 (== stage of tile t+D) is free
-        if (t + D < ktiles && !(map_mode & 0x100)) issue(stn, (kt0 + t + D) * G_BK);  // 0x100: ablation (PPLHIP_GEMM_ABLATE)
+        if constexpr (WL != 5) if (t + D < ktiles && !(map_mode & 0x100)) issue(stn, (kt0 + t + D) * G_BK);  // 0x100: ablation (PPLHIP_GEMM_ABLATE)
         const uint16_t* xs = Xs0 + st * (G_BM * G_BK);
         const char* wq = Wq0 + st * W_STAGE;
         st = st == G_ST - 1 ? 0 : st + 1;
@@ -400,23 +414,14 @@ __global__ __launch_bounds__(WL == 2 ? 512 : 256) void gemm_dma_kernel(const uin
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int row = nb + i * 16 + l15;
-                if constexpr (WL == 2) {  // only this wave's k-slice: 8 of the 16 bytes
-                    const uint2 v = *reinterpret_cast<const uint2*>(&wq[row * G_BK + (kq ^ w_swz(row)) * 16 + kg * 8]);
-                    wraw[i].x = v.x; wraw[i].y = v.y;
-                } else {
-                    wraw[i] = *reinterpret_cast<const uint4*>(&wq[row * G_BK + (kq ^ w_swz(row)) * 16]);
-                }
+                wraw[i] = *reinterpret_cast<const uint4*>(&wq[row * G_BK + (kq ^ w_swz(row)) * 16]);
             }
         } else if constexpr (WQ == 4) {
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int row = nb + i * 16 + l15;
-                if constexpr (WL == 2) {
-                    wraw[i].x = *reinterpret_cast<const uint32_t*>(&wq[row * 32 + ((kq ^ (((row >> 3) & 1) << 1)) * 8) + kg * 4]);
-                } else {
-                    const uint2 v = *reinterpret_cast<const uint2*>(&wq[row * 32 + ((kq ^ (((row >> 3) & 1) << 1)) * 8)]);
-                    wraw[i].x = v.x; wraw[i].y = v.y;
-                }
+                const uint2 v = *reinterpret_cast<const uint2*>(&wq[row * 32 + ((kq ^ (((row >> 3) & 1) << 1)) * 8)]);
+                wraw[i].x = v.x; wraw[i].y = v.y;
             }
             if ((t & 1) == 0) {
 #pragma unroll
@@ -427,15 +432,14 @@ __global__ __launch_bounds__(WL == 2 ? 512 : 256) void gemm_dma_kernel(const uin
             }
         }
 #pragma unroll
-        for (int kk = 0; kk < (WL == 2 ? 1 : 2); ++kk) {
-            const int ks = WL == 2 ? kg : kk;
+        for (int ks = 0; ks < 2; ++ks) {
             h8 a[NI], bfr[NJ];
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 if constexpr (WQ == 8) {
-                    a[i] = cvt_i8x8_f16((WL == 2 || ks == 0) ? make_uint2(wraw[i].x, wraw[i].y) : make_uint2(wraw[i].z, wraw[i].w));
+                    a[i] = cvt_i8x8_f16(ks == 0 ? make_uint2(wraw[i].x, wraw[i].y) : make_uint2(wraw[i].z, wraw[i].w));
                 } else if constexpr (WQ == 4) {
-                    a[i] = cvt_i4x8_f16((WL == 2 || ks == 0) ? wraw[i].x : wraw[i].y, gsc[i]);
+                    a[i] = cvt_i4x8_f16(ks == 0 ? wraw[i].x : wraw[i].y, gsc[i]);
                 } else {
                     const int row = nb + i * 16 + l15;
                     a[i] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&wq[(row * G_BK + g_swz(row, ks * 4 + kq) * 8) * 2]));
@@ -453,34 +457,12 @@ __global__ __launch_bounds__(WL == 2 ? 512 : 256) void gemm_dma_kernel(const uin
         }
     }
 
-    if constexpr (WL == 2) {
-        // exchange of the two k-slices' partial sums: fragment row i goes to the waves of slice i, which then own the
-        // rows nb + i*16 .. +16 of the tile.  32 KiB of the (now idle) stage buffers per pass.
-        float4* xb = reinterpret_cast<float4*>(smem);
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            __syncthreads();
-            if (kg != pass) {
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    xb[(wn * NJ + j) * 64 + lane] = make_float4(acc[pass][j][0], acc[pass][j][1], acc[pass][j][2], acc[pass][j][3]);
-            }
-            __syncthreads();
-            if (kg == pass) {
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const float4 o = xb[(wn * NJ + j) * 64 + lane];
-                    acc[pass][j][0] += o.x; acc[pass][j][1] += o.y; acc[pass][j][2] += o.z; acc[pass][j][3] += o.w;
-                }
-            }
-        }
-    }
     if (gridDim.y > 1) {  // fp32 partial slab [split][M][N]
         float* slab = ws + (int64_t)blockIdx.y * M * N;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int n = n0 + nb + i * 16 + kq * 4;
-            if (n >= N || (WL == 2 && i != kg)) continue;
+            if (n >= N) continue;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int64_t m = m0 + mb + j * 16 + l15;
@@ -492,7 +474,7 @@ __global__ __launch_bounds__(WL == 2 ? 512 : 256) void gemm_dma_kernel(const uin
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int n = n0 + nb + i * 16 + kq * 4;
-        if (n >= N || (WL == 2 && i != kg)) continue;
+        if (n >= N) continue;
         h4 sh = {(_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f};
         if constexpr (WQ == 8) sh = __builtin_bit_cast(h4, *reinterpret_cast<const uint2*>(scale + n));
 #pragma unroll
@@ -846,12 +828,13 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         splits = (kt_all + kt_per - 1) / kt_per;  // no empty split
         if (splits > 1) stages = 2;
         g2.y = splits;
-        // wave layout: at most one block per CU (<= 256 tiles) -> 8 waves with the K tile sliced across them (two waves
-        // per SIMD from the one block); more tiles -> 4 waves of 32(n) x 128(m), two blocks per CU
+        // at most one block per CU (<= 256 blocks): 8 waves, 4 of them producers that only issue the ring's LDS-DMA (two waves
+        // per SIMD from the one block, the DMA issue runs beside the MFMA stream: wo 59 -> 46 us, w2 120 -> 95 us at
+        // M = 1024); more blocks: 4 waves of 32(n) x 128(m), two blocks per CU (the specialised form is not faster there)
         static const int forced_wl = getenv("PPLHIP_GEMM_WL") ? atoi(getenv("PPLHIP_GEMM_WL")) : 0;
-        const int wl = forced_wl ? forced_wl : (tiles * splits <= 256 ? 2 : 1);
+        const int wl = (forced_wl == 1 || forced_wl == 5) ? forced_wl : (tiles * splits <= 256 ? 5 : 1);
 #define DMA_LAUNCH(WQ, O32, ST)                                                                                     \
-    do { if (wl == 2) hipLaunchKernelGGL((gemm_dma_kernel<WQ, O32, ST, 2>), g2, dim3(512), 0, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles, map_mode, kt_per, ws); \
+    do { if (wl == 5) hipLaunchKernelGGL((gemm_dma_kernel<WQ, O32, ST, 5>), g2, dim3(512), 0, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles, map_mode, kt_per, ws); \
          else hipLaunchKernelGGL((gemm_dma_kernel<WQ, O32, ST, 1>), g2, block, 0, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles, map_mode, kt_per, ws); } while (0)
 #define DMA_STAGES(WQ, O32)                                                                                         \
     do { if (stages == 2) DMA_LAUNCH(WQ, O32, 2); else if (stages == 3) DMA_LAUNCH(WQ, O32, 3); else DMA_LAUNCH(WQ, O32, 4); } while (0)
