@@ -19,11 +19,11 @@ DIMS = dict(hidden_dim=4096, intermediate_dim=11008, num_layers=32, num_heads=32
 I64MAX = np.iinfo(np.int64).max
 
 
-def make_ctx(m, layout=3, mode=0, page=16, batch=16, tokens=2048, kv_tokens=8192, **over):
+def make_ctx(m, layout=3, mode=0, page=16, batch=16, tokens=2048, kv_tokens=8192, wq=8, **over):
     kw = dict(DIMS)
     kw.update(over)
     desc = m.make_desc(max_position=4096, cache_quant_bit=8, cache_quant_group=8, cache_layout=layout, cache_mode=mode,
-                       page_size=page if mode else 0, weight_quant_bit=8, **kw)
+                       page_size=page if mode else 0, weight_quant_bit=wq, weight_quant_group=128, **kw)
     ctx = m.Context(desc, max_running_batch=batch, max_tokens_per_step=tokens)
     ctx.init_synthetic(0, 4321)
     ctx.kv_alloc(0, kv_tokens)
@@ -157,3 +157,32 @@ def test_gemm_linearity_and_path_agreement():
     ref8 = outs[8]
     for M in (100, 1024):
         assert np.abs(outs[M] - ref8).max() <= 2e-3 * max(1.0, np.abs(ref8).max())
+
+
+def test_grouped_query_w4_model_invariances(prompts):
+    """the same invariants on a grouped-query, W4A16-g128 model at 70B-like head geometry (8 query heads per KV head,
+    head_dim 128, hidden 4096, 8 layers): decode rows run the MFMA grouped-query kernel, the GEMMs the int4 tile path."""
+    m = load_pplhip()
+    over = dict(num_kv_heads=4, num_layers=8, wq=4)
+    ref_l = None
+    for layout, mode in [(3, 0), (1, 1), (3, 1)]:
+        ctx = make_ctx(m, layout=layout, mode=mode, **over)
+        l0, l1 = run_two_steps(m, ctx, prompts, mode, 16, 8192)
+        if ref_l is None:
+            order = np.array([3, 0, 5, 1, 4, 2])
+            c0, c1 = run_two_steps(m, ctx, prompts, mode, 16, 8192, order=order)
+            assert (c0 == l0[order]).all() and (c1 == l1[order]).all()     # permutation equivariance, bit for bit
+            # prefill n+1 == prefill n, then decode 1 (MFMA prefill kernel vs MFMA grouped-query decode kernel)
+            p = prompts[2]
+            ext = np.concatenate([p, [(7 * int(p[-1]) + 11) % 32000]])
+            ctx.set_inputs(0, m.make_step(ext, [0, len(ext)], [0], [4096], 0))
+            ctx.run(0)
+            full = ctx.copy_logits(1)[0]
+            scale = max(1.0, np.abs(full).max())
+            assert np.abs(full - l1[2]).max() <= 1.5e-2 * scale
+        ctx.close()
+        assert np.isfinite(l0).all() and np.isfinite(l1).all()
+        if ref_l is None:
+            ref_l = (l0, l1)
+        else:
+            assert (l0 == ref_l[0]).all() and (l1 == ref_l[1]).all(), (layout, mode)
