@@ -16,6 +16,7 @@
 //   is applied identically to the V^T reads).
 //   int8 KV is dequantised to fp16 while staging (one fp16 rounding of q*scale; DESIGN.md "numerics").
 // Oracle: ref_attention (oracle/llama_ref.c).
+#include <stdlib.h>
 #include <type_traits>
 #include "kernels.h"
 
@@ -34,8 +35,11 @@ __device__ __forceinline__ int k_swz(int key) {
 }
 __device__ __forceinline__ int v_swz(int ch) { return ((ch >> 4) & 7) << 2; }
 
-template <int QBIT, int D, int MODE>  // MODE = cache_mode (0 contiguous slots, 1 paged): a compile-time split keeps the
-                                      // page-table load and its wait out of the contiguous kernel's prefetch pipeline
+// MODE = cache_mode (0 contiguous slots, 1 paged): a compile-time split keeps the page-table load and its wait out of the
+// contiguous kernel's prefetch pipeline.  RG = groups of 16 query rows per wave (block = 128 * RG rows): with RG = 2 every staged
+// K/V tile (dequantisation + LDS writes by all 512 threads) and every K / V^T fragment read feeds twice the MFMAs -- used for
+// long prompts, where the staging is what bounds the kernel.
+template <int QBIT, int D, int MODE, int RG>
 __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t* __restrict__ qkv, KvAddr kv,
                                                                   const int64_t* __restrict__ seq_starts,
                                                                   const int64_t* __restrict__ start_pos,
@@ -51,12 +55,15 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
     constexpr int IPT = (NITEMS + PF_THREADS - 1) / PF_THREADS;              // items per thread (1 or 2)
     __shared__ __attribute__((aligned(16))) uint16_t Ks[PF_BN * D];
     __shared__ __attribute__((aligned(16))) uint32_t Vt[D * PF_VS];
+    // RG = 2: the Q fragments live in LDS (64 KiB, same chunk swizzle as K) instead of 32 more VGPRs per lane
+    __shared__ __attribute__((aligned(16))) uint16_t Qs[RG > 1 ? PF_BM * RG * D : 8];
 
     const int64_t b = b0 + blockIdx.y;
     const int hq = blockIdx.z;
     const int hk = hq / (H / Hkv);
     const int64_t seqlen = seq_starts[b + 1] - seq_starts[b];
-    const int64_t q0 = (int64_t)blockIdx.x * PF_BM;
+    constexpr int BM = PF_BM * RG;
+    const int64_t q0 = (int64_t)blockIdx.x * BM;
     if (q0 >= seqlen) return;
     const int64_t sp = start_pos[b];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -64,25 +71,39 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
     const int64_t rowstride = (int64_t)(H + 2 * Hkv) * D;
 
     // Q fragments: B operand, lane (n = query row l15, kq) holds Q[row][ks*32 + kq*8 .. +8]
-    int64_t qi = q0 + wave * 16 + l15;
-    if (qi >= seqlen) qi = seqlen - 1;
-    const int64_t qpos = sp + qi;
-    const uint16_t* qrow = qkv + (seq_starts[b] + qi) * rowstride + (int64_t)hq * D;
-    h8 qf[KSTEPS];
+    const int64_t wrow0 = q0 + wave * (16 * RG);  // first query row of this wave; group g covers wrow0 + 16 g .. + 16
+    int64_t qpos[RG];
+    h8 qf[RG > 1 ? 1 : RG][KSTEPS];
+    f4 o[RG][DT];
+    float m[RG], l[RG];
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(qrow + ks * 32 + kq * 8));
-
-    f4 o[DT];
+    for (int g = 0; g < RG; ++g) {
+        int64_t qi = wrow0 + g * 16 + l15;
+        if (qi >= seqlen) qi = seqlen - 1;
+        qpos[g] = sp + qi;
+        const uint16_t* qrow = qkv + (seq_starts[b] + qi) * rowstride + (int64_t)hq * D;
 #pragma unroll
-    for (int i = 0; i < DT; ++i) o[i] = f4{0.f, 0.f, 0.f, 0.f};
-    float m = -1e30f, l = 0.f;
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const uint4 v = *reinterpret_cast<const uint4*>(qrow + ks * 32 + kq * 8);
+            if constexpr (RG > 1) {
+                const int row = wave * (16 * RG) + g * 16 + l15;  // only this wave reads these rows back: no barrier needed
+                *reinterpret_cast<uint4*>(&Qs[row * D + ((ks * 4 + kq) ^ k_swz<D>(row)) * 8]) = v;
+            } else {
+                qf[g][ks] = __builtin_bit_cast(h8, v);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < DT; ++i) o[g][i] = f4{0.f, 0.f, 0.f, 0.f};
+        m[g] = -1e30f;
+        l[g] = 0.f;
+    }
     const float sm_scale = 1.0f / sqrtf((float)D);
 
-    const int64_t last_q = (q0 + PF_BM - 1 < seqlen - 1) ? q0 + PF_BM - 1 : seqlen - 1;
+    const int64_t last_q = (q0 + BM - 1 < seqlen - 1) ? q0 + BM - 1 : seqlen - 1;
     const int64_t kv_end = sp + last_q + 1;   // keys needed by this block: [0, kv_end)
     const int ntiles = (int)((kv_end + PF_BN - 1) / PF_BN);
     // waves whose 16 rows lie entirely beyond the sequence still help staging but skip the MFMAs
-    const bool wave_active = (q0 + wave * 16) < seqlen;
+    const bool wave_active = wrow0 < seqlen;
 
     const int64_t slot0 = MODE == 0 ? cache_indices[b] : 0;  // contiguous mode: first slot of the request
     const char* kbase = reinterpret_cast<const char*>(kv.cache) + (int64_t)hk * kv.sH * ELT;
@@ -164,12 +185,17 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
         __syncthreads();
         if (tile + 1 < ntiles) load_tile(tile + 1);  // in flight during the MFMAs below
 
-        // a wave whose rows all end before this tile starts has nothing to add (causal)
-        if (wave_active && key0 <= sp + ((q0 + wave * 16 + 15 < seqlen - 1) ? q0 + wave * 16 + 15 : seqlen - 1)) {
-            // ---- S^T = K . Q^T : 8 key tiles of 16 ---------------------------------------------------------
-            f4 sacc[8];
+        // a wave whose rows all end before this tile starts has nothing to add (causal); inside an active wave a row group
+        // that lies before the tile is merely masked (alpha = 1, all probabilities 0)
+        const int64_t wlast = (wrow0 + 16 * RG - 1 < seqlen - 1) ? wrow0 + 16 * RG - 1 : seqlen - 1;
+        if (wave_active && key0 <= sp + wlast) {
+            // ---- S^T = K . Q^T : 8 key tiles of 16; every K fragment feeds the RG row groups ------------------
+            f4 sacc[RG][8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sacc[j] = f4{0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < RG; ++g)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sacc[g][j] = f4{0.f, 0.f, 0.f, 0.f};
+            h8 qk[RG];  // RG = 2: this k-step's Q fragments, fetched from LDS
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
 #pragma unroll
@@ -177,55 +203,71 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
                     const int key = j * 16 + l15;
                     const int chunk = (ks * 4 + kq) ^ k_swz<D>(key);
                     const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&Ks[key * D + chunk * 8]));
-                    sacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[ks], sacc[j], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < RG; ++g) {
+                        if constexpr (RG > 1) {
+                            if (j == 0) {
+                                const int row = wave * (16 * RG) + g * 16 + l15;
+                                qk[g] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&Qs[row * D + ((ks * 4 + kq) ^ k_swz<D>(row)) * 8]));
+                            }
+                            sacc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qk[g], sacc[g][j], 0, 0, 0);
+                        } else {
+                            sacc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[g][ks], sacc[g][j], 0, 0, 0);
+                        }
+                    }
                 }
             }
-            // ---- online softmax for query row l15; this lane holds keys j*16 + kq*4 + r ---------------------
-            float mx = -1e30f;
+            // ---- online softmax for query row l15 of each group; this lane holds keys j*16 + kq*4 + r --------
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int g = 0; g < RG; ++g) {
+                float mx = -1e30f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t kpos = key0 + j * 16 + kq * 4 + r;
-                    const float sv = (kpos <= qpos) ? sacc[j][r] * sm_scale : -1e30f;
-                    sacc[j][r] = sv;
-                    mx = fmaxf(mx, sv);
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mnew = fmaxf(m, mx);
-            const float alpha = __expf(m - mnew);
-            m = mnew;
-            float rs = 0.f;
+                for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t kpos = key0 + j * 16 + kq * 4 + r;
+                        const float sv = (kpos <= qpos[g]) ? sacc[g][j][r] * sm_scale : -1e30f;
+                        sacc[g][j][r] = sv;
+                        mx = fmaxf(mx, sv);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float mnew = fmaxf(m[g], mx);
+                const float alpha = __expf(m[g] - mnew);
+                m[g] = mnew;
+                float rs = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t kpos = key0 + j * 16 + kq * 4 + r;
-                    const float e = (kpos <= qpos) ? __expf(sacc[j][r] - mnew) : 0.f;
-                    sacc[j][r] = e;
-                    rs += e;
-                }
-            rs += __shfl_xor(rs, 16, 64);
-            rs += __shfl_xor(rs, 32, 64);
-            l = l * alpha + rs;
-            // rescale O: its C layout has rows (kq*4 + r) -> fetch alpha of those query rows
-            float ar[4];
+                for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, kq * 4 + r, 64);
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t kpos = key0 + j * 16 + kq * 4 + r;
+                        const float e = (kpos <= qpos[g]) ? __expf(sacc[g][j][r] - mnew) : 0.f;
+                        sacc[g][j][r] = e;
+                        rs += e;
+                    }
+                rs += __shfl_xor(rs, 16, 64);
+                rs += __shfl_xor(rs, 32, 64);
+                l[g] = l[g] * alpha + rs;
+                // rescale O: its C layout has rows (kq*4 + r) -> fetch alpha of those query rows
+                float ar[4];
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+                for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, kq * 4 + r, 64);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[dt][r] *= ar[r];
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[g][dt][r] *= ar[r];
+            }
             // ---- O += P . V : A = P (this lane's 8 keys per k-step: tiles 2s, 2s+1), B = V^T from LDS ---------
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) {
-                h8 pa;
+                h8 pa[RG];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pa[r] = (_Float16)sacc[2 * s2][r];
-                    pa[4 + r] = (_Float16)sacc[2 * s2 + 1][r];
-                }
+                for (int g = 0; g < RG; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pa[g][r] = (_Float16)sacc[g][2 * s2][r];
+                        pa[g][4 + r] = (_Float16)sacc[g][2 * s2 + 1][r];
+                    }
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
                     const int ch = dt * 16 + l15;
@@ -234,24 +276,28 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
                     const uint2 lo = *reinterpret_cast<const uint2*>(&Vt[ch * PF_VS + p0]);
                     const uint2 hi = *reinterpret_cast<const uint2*>(&Vt[ch * PF_VS + p1]);
                     const h8 bv = __builtin_bit_cast(h8, make_uint4(lo.x, lo.y, hi.x, hi.y));
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, bv, o[dt], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < RG; ++g) o[g][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa[g], bv, o[g][dt], 0, 0, 0);
                 }
             }
         }
         __syncthreads();
     }
-    // ---- epilogue: O / l, fp16, rows kq*4 + r of this wave -------------------------------------------------
-    float lr[4];
+    // ---- epilogue: O / l, fp16, rows kq*4 + r of every group of this wave ------------------------------------------
 #pragma unroll
-    for (int r = 0; r < 4; ++r) lr[r] = __shfl(l, kq * 4 + r, 64);
+    for (int g = 0; g < RG; ++g) {
+        float lr[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int64_t qrow_i = q0 + wave * 16 + kq * 4 + r;
-        if (qrow_i < seqlen) {
-            uint16_t* orow = out + ((seq_starts[b] + qrow_i) * H + hq) * (int64_t)D;
-            const float inv = 1.0f / lr[r];
+        for (int r = 0; r < 4; ++r) lr[r] = __shfl(l[g], kq * 4 + r, 64);
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) orow[dt * 16 + l15] = f2h(o[dt][r] * inv);
+        for (int r = 0; r < 4; ++r) {
+            const int64_t qrow_i = wrow0 + g * 16 + kq * 4 + r;
+            if (qrow_i < seqlen) {
+                uint16_t* orow = out + ((seq_starts[b] + qrow_i) * H + hq) * (int64_t)D;
+                const float inv = 1.0f / lr[r];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) orow[dt * 16 + l15] = f2h(o[g][dt][r] * inv);
+            }
         }
     }
 }
@@ -261,14 +307,22 @@ hipError_t launch_attn_prefill(hipStream_t s, const uint16_t* qkv, const KvAddr&
                                int64_t max_pages, int64_t b0, int64_t B, int H, int Hkv, int D, int64_t max_seq_len,
                                uint16_t* out) {
     if (B <= b0 || max_seq_len <= 0) return hipSuccess;
-    dim3 grid((unsigned)((max_seq_len + PF_BM - 1) / PF_BM), (unsigned)(B - b0), (unsigned)H);
+    // long prompts: 256 query rows per block (two row groups per wave); short ones keep 128 so that fewer rows are padding
+    static const int forced_rg = getenv("PPLHIP_PREFILL_RG") ? atoi(getenv("PPLHIP_PREFILL_RG")) : 0;
+    const int rg = forced_rg ? forced_rg : (max_seq_len >= 1024 ? 2 : 1);
+    const int bm = PF_BM * rg;
+    dim3 grid((unsigned)((max_seq_len + bm - 1) / bm), (unsigned)(B - b0), (unsigned)H);
+#define PF_LAUNCH(QB, DD, MD, RGV)                                                                                     \
+    hipLaunchKernelGGL((attn_prefill_kernel<QB, DD, MD, RGV>), grid, dim3(PF_THREADS), 0, s, qkv, kv, seq_starts, start_pos, \
+                       cache_indices, max_pages, b0, H, Hkv, out)
 #define PF_CASE(QB, DD)                                                                                          \
     if (quant_bit == QB && D == DD) {                                                                            \
-        if (kv.mode == 0) hipLaunchKernelGGL((attn_prefill_kernel<QB, DD, 0>), grid, dim3(PF_THREADS), 0, s, qkv, kv, seq_starts, start_pos, cache_indices, max_pages, b0, H, Hkv, out); \
-        else hipLaunchKernelGGL((attn_prefill_kernel<QB, DD, 1>), grid, dim3(PF_THREADS), 0, s, qkv, kv, seq_starts, start_pos, cache_indices, max_pages, b0, H, Hkv, out); \
+        if (kv.mode == 0) { if (rg == 2) PF_LAUNCH(QB, DD, 0, 2); else PF_LAUNCH(QB, DD, 0, 1); }                \
+        else { if (rg == 2) PF_LAUNCH(QB, DD, 1, 2); else PF_LAUNCH(QB, DD, 1, 1); }                             \
         return hipGetLastError();                                                                                \
     }
     PF_CASE(8, 128) PF_CASE(0, 128) PF_CASE(8, 64) PF_CASE(0, 64) PF_CASE(8, 32) PF_CASE(0, 32)
+#undef PF_LAUNCH
 #undef PF_CASE
     return hipErrorInvalidValue;
 }
