@@ -63,7 +63,9 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
     const int hk = hq / (H / Hkv);
     const int64_t seqlen = seq_starts[b + 1] - seq_starts[b];
     constexpr int BM = PF_BM * RG;
-    const int64_t q0 = (int64_t)blockIdx.x * BM;
+    // causal work grows with the query tile index: the heaviest tiles are dispatched first (blockIdx.x = 0 is the LAST tile),
+    // so the launch ends with light blocks instead of a few CUs finishing 64-tile blocks alone
+    const int64_t q0 = (int64_t)(gridDim.x - 1 - blockIdx.x) * BM;
     if (q0 >= seqlen) return;
     const int64_t sp = start_pos[b];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
         m[g] = -1e30f;
         l[g] = 0.f;
     }
-    const float sm_scale = 1.0f / sqrtf((float)D);
+    const float sm_scale2 = 1.4426950408889634f / sqrtf((float)D);  // softmax scale x log2(e)
 
     const int64_t last_q = (q0 + BM - 1 < seqlen - 1) ? q0 + BM - 1 : seqlen - 1;
     const int64_t kv_end = sp + last_q + 1;   // keys needed by this block: [0, kv_end)
@@ -218,44 +220,60 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
                 }
             }
             // ---- online softmax for query row l15 of each group; this lane holds keys j*16 + kq*4 + r --------
+            // scores are kept in the log2 domain (scale * log2(e) folded into one multiply, v_exp_f32 is 2^x); the causal
+            // mask costs two VALU per score and is only applied on tiles that reach the wave's diagonal
+            const bool need_mask = key0 + PF_BN - 1 > sp + wrow0;  // wave-uniform: some key of the tile may exceed a row's position
 #pragma unroll
             for (int g = 0; g < RG; ++g) {
                 float mx = -1e30f;
+                if (need_mask) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                    for (int j = 0; j < 8; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int64_t kpos = key0 + j * 16 + kq * 4 + r;
-                        const float sv = (kpos <= qpos[g]) ? sacc[g][j][r] * sm_scale : -1e30f;
-                        sacc[g][j][r] = sv;
-                        mx = fmaxf(mx, sv);
-                    }
+                        for (int r = 0; r < 4; ++r) {
+                            const int64_t kpos = key0 + j * 16 + kq * 4 + r;
+                            const float sv = (kpos <= qpos[g]) ? sacc[g][j][r] * sm_scale2 : -1e30f;
+                            sacc[g][j][r] = sv;
+                            mx = fmaxf(mx, sv);
+                        }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float sv = sacc[g][j][r] * sm_scale2;
+                            sacc[g][j][r] = sv;
+                            mx = fmaxf(mx, sv);
+                        }
+                }
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 const float mnew = fmaxf(m[g], mx);
-                const float alpha = __expf(m[g] - mnew);
+                const float alpha = __builtin_amdgcn_exp2f(m[g] - mnew);
                 m[g] = mnew;
                 float rs = 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int64_t kpos = key0 + j * 16 + kq * 4 + r;
-                        const float e = (kpos <= qpos[g]) ? __expf(sacc[g][j][r] - mnew) : 0.f;
+                        const float e = __builtin_amdgcn_exp2f(sacc[g][j][r] - mnew);  // masked scores: 2^(-1e30 - m) = 0
                         sacc[g][j][r] = e;
                         rs += e;
                     }
                 rs += __shfl_xor(rs, 16, 64);
                 rs += __shfl_xor(rs, 32, 64);
                 l[g] = l[g] * alpha + rs;
-                // rescale O: its C layout has rows (kq*4 + r) -> fetch alpha of those query rows
-                float ar[4];
+                // rescale O only when some row's maximum moved (rare after the first tiles): its C layout has rows
+                // (kq*4 + r) -> fetch alpha of those query rows
+                if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+                    float ar[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, kq * 4 + r, 64);
+                    for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, kq * 4 + r, 64);
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
+                    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[g][dt][r] *= ar[r];
+                        for (int r = 0; r < 4; ++r) o[g][dt][r] *= ar[r];
+                }
             }
             // ---- O += P . V : A = P (this lane's 8 keys per k-step: tiles 2s, 2s+1), B = V^T from LDS ---------
 #pragma unroll
@@ -307,9 +325,11 @@ hipError_t launch_attn_prefill(hipStream_t s, const uint16_t* qkv, const KvAddr&
                                int64_t max_pages, int64_t b0, int64_t B, int H, int Hkv, int D, int64_t max_seq_len,
                                uint16_t* out) {
     if (B <= b0 || max_seq_len <= 0) return hipSuccess;
-    // long prompts: 256 query rows per block (two row groups per wave); short ones keep 128 so that fewer rows are padding
+    // RG = 2 (256 query rows per block, Q fragments in LDS) halves the staging per MFMA but spills registers and measured
+    // slower than RG = 1 once the softmax was trimmed (8192-token prompt: 1.86 ms vs 1.43 ms per layer); PPLHIP_PREFILL_RG=2 keeps
+    // it reachable for experiments
     static const int forced_rg = getenv("PPLHIP_PREFILL_RG") ? atoi(getenv("PPLHIP_PREFILL_RG")) : 0;
-    const int rg = forced_rg ? forced_rg : (max_seq_len >= 1024 ? 2 : 1);
+    const int rg = forced_rg == 2 ? 2 : 1;
     const int bm = PF_BM * rg;
     dim3 grid((unsigned)((max_seq_len + bm - 1) / bm), (unsigned)(B - b0), (unsigned)H);
 #define PF_LAUNCH(QB, DD, MD, RGV)                                                                                     \
