@@ -6,7 +6,7 @@
 // Work decomposition (wave64, gfx950, mfma_f32_16x16x32_f16):
 //   grid  = (ceil(max_seq_len / 128), requests, H); block = 8 waves; wave w owns 16 query rows.
 //   per KV tile of 128 keys:  K tile -> LDS as fp16 [key][D] (16-B chunks XOR-swizzled against bank conflicts),
-//                             V tile -> LDS TRANSPOSED [d][key] (key-pair dwords, XOR-swizzled) because the PV
+//                             V tile -> LDS row-major [16 keys][16 channels] sub-tiles, read TRANSPOSED (ds_read_b64_tr_b16) because the PV
 //                             MFMA contracts over keys and needs them contiguous per lane.
 //   The tile is staged global -> registers -> LDS; the loads of tile t+1 are issued BEFORE the MFMAs of tile t and
 //   converted / written after them (register prefetch, T14 of the CDNA guide), so HBM/L2 latency hides under compute.
@@ -24,7 +24,7 @@ namespace pplhip {
 
 constexpr int PF_BM = 128;  // query rows per block
 constexpr int PF_BN = 128;  // keys per tile
-constexpr int PF_VS = 66;   // dword stride of a V^T row (128 keys = 64 dwords + 2 pad)
+constexpr int PF_VSUB = 272;  // halfs per [16 keys][16 channels] V sub-tile in LDS: 256 + 16 of skew (bank spread of the writes)
 constexpr int PF_THREADS = 512;
 
 template <int D>
@@ -33,7 +33,16 @@ __device__ __forceinline__ int k_swz(int key) {
     constexpr int RPW = (128 / D) > 0 ? (128 / D) : 1; // rows per 256-B bank window
     return (key / RPW) % CPR;
 }
-__device__ __forceinline__ int v_swz(int ch) { return ((ch >> 4) & 7) << 2; }
+// V tile in LDS: row-major [16 keys][16 channels] fp16 sub-tiles, sub-tile (kt, dt) at (kt * D/16 + dt) * PF_VSUB halfs.  The P.V
+// MFMA contracts over keys, so its B operand wants 4 keys of ONE channel per lane: gfx950's transposing LDS read delivers exactly
+// that from the row-major image (lane l of a 16-lane group supplies the address of row l/4, columns (l%4)*4.. and receives column l
+// of the [4][16] block -- profiles/probes/lds_tr_read_probe.hip), so the staging writes V like K (16-byte stores, no shuffling).
+typedef short pf_s4 __attribute__((__vector_size__(4 * sizeof(short))));
+__device__ __forceinline__ uint2 v_frag_tr(const uint16_t* vs, int sub, int kq, int l15) {
+    const uint16_t* p = vs + sub * PF_VSUB + (kq * 4 + (l15 >> 2)) * 16 + (l15 & 3) * 4;
+    const pf_s4 w = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) pf_s4*)p);
+    return __builtin_bit_cast(uint2, w);
+}
 
 // MODE = cache_mode (0 contiguous slots, 1 paged): a compile-time split keeps the page-table load and its wait out of the
 // contiguous kernel's prefetch pipeline.  RG = groups of 16 query rows per wave (block = 128 * RG rows): with RG = 2 every staged
@@ -54,7 +63,7 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
     constexpr int NITEMS = (PF_BN / 2) * LPT;                                // (key pair, piece) staging items per tile
     constexpr int IPT = (NITEMS + PF_THREADS - 1) / PF_THREADS;              // items per thread (1 or 2)
     __shared__ __attribute__((aligned(16))) uint16_t Ks[PF_BN * D];
-    __shared__ __attribute__((aligned(16))) uint32_t Vt[D * PF_VS];
+    __shared__ __attribute__((aligned(16))) uint16_t Vs[(PF_BN / 16) * (D / 16) * PF_VSUB];
     // RG = 2: the Q fragments live in LDS (64 KiB, same chunk swizzle as K) instead of 32 more VGPRs per lane
     __shared__ __attribute__((aligned(16))) uint16_t Qs[RG > 1 ? PF_BM * RG * D : 8];
 
@@ -171,10 +180,14 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < CH; ++i) {
-                    const int ch = ch0 + i;
-                    const h2 pr = {vh[0][i >> 3][i & 7], vh[1][i >> 3][i & 7]};
-                    Vt[ch * PF_VS + (kp ^ v_swz(ch))] = __builtin_bit_cast(uint32_t, pr);
+                for (int e = 0; e < 2; ++e) {
+                    const int key = 2 * kp + e;
+#pragma unroll
+                    for (int cc = 0; cc < CH / 8; ++cc) {
+                        const int ch = ch0 + cc * 8;
+                        *reinterpret_cast<uint4*>(&Vs[((key >> 4) * (D / 16) + (ch >> 4)) * PF_VSUB + (key & 15) * 16 + (ch & 15)]) =
+                            __builtin_bit_cast(uint4, vh[e][cc]);
+                    }
                 }
             }
         }
@@ -288,11 +301,8 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
                     }
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    const int ch = dt * 16 + l15;
-                    const int p0 = (8 * (2 * s2) + kq * 2) ^ v_swz(ch);      // dword index of keys 16*(2s)+kq*4
-                    const int p1 = (8 * (2 * s2 + 1) + kq * 2) ^ v_swz(ch);
-                    const uint2 lo = *reinterpret_cast<const uint2*>(&Vt[ch * PF_VS + p0]);
-                    const uint2 hi = *reinterpret_cast<const uint2*>(&Vt[ch * PF_VS + p1]);
+                    const uint2 lo = v_frag_tr(Vs, (2 * s2) * DT + dt, kq, l15);      // keys 16*(2s) + kq*4 .. +4 of channel dt*16 + l15
+                    const uint2 hi = v_frag_tr(Vs, (2 * s2 + 1) * DT + dt, kq, l15);
                     const h8 bv = __builtin_bit_cast(h8, make_uint4(lo.x, lo.y, hi.x, hi.y));
 #pragma unroll
                     for (int g = 0; g < RG; ++g) o[g][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa[g], bv, o[g][dt], 0, 0, 0);
@@ -370,11 +380,11 @@ __global__ __launch_bounds__(PF_THREADS) void attn_decode_gqa_kernel(const uint1
     constexpr int NITEMS = (PF_BN / 2) * LPT;
     constexpr int IPT = (NITEMS + PF_THREADS - 1) / PF_THREADS;
     // one LDS object: K tile | V^T tile during the loop, the per-wave partial results afterwards
-    constexpr int KS_BYTES = PF_BN * D * 2, VT_BYTES = D * PF_VS * 4, MERGE_BYTES = 8 * 16 * (D + 2) * 4;
+    constexpr int KS_BYTES = PF_BN * D * 2, VT_BYTES = (PF_BN / 16) * (D / 16) * PF_VSUB * 2, MERGE_BYTES = 8 * 16 * (D + 2) * 4;
     constexpr int LDS_BYTES = (KS_BYTES + VT_BYTES) > MERGE_BYTES ? (KS_BYTES + VT_BYTES) : MERGE_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
     uint16_t* const Ks = reinterpret_cast<uint16_t*>(smem);
-    uint32_t* const Vt = reinterpret_cast<uint32_t*>(smem + KS_BYTES);
+    uint16_t* const Vs = reinterpret_cast<uint16_t*>(smem + KS_BYTES);
 
     const int hk = blockIdx.x;
     const int64_t b = blockIdx.y;
@@ -469,10 +479,14 @@ __global__ __launch_bounds__(PF_THREADS) void attn_decode_gqa_kernel(const uint1
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < CH; ++i) {
-                    const int ch = ch0 + i;
-                    const h2 pr = {vh[0][i >> 3][i & 7], vh[1][i >> 3][i & 7]};
-                    Vt[ch * PF_VS + (kp ^ v_swz(ch))] = __builtin_bit_cast(uint32_t, pr);
+                for (int e = 0; e < 2; ++e) {
+                    const int key = 2 * kp + e;
+#pragma unroll
+                    for (int cc = 0; cc < CH / 8; ++cc) {
+                        const int ch = ch0 + cc * 8;
+                        *reinterpret_cast<uint4*>(&Vs[((key >> 4) * (D / 16) + (ch >> 4)) * PF_VSUB + (key & 15) * 16 + (ch & 15)]) =
+                            __builtin_bit_cast(uint4, vh[e][cc]);
+                    }
                 }
             }
         }
@@ -539,9 +553,7 @@ __global__ __launch_bounds__(PF_THREADS) void attn_decode_gqa_kernel(const uint1
                      (_Float16)0.f, (_Float16)0.f};
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const int ch = dt * 16 + l15;
-                const int p0 = (8 * wave + kq * 2) ^ v_swz(ch);  // dword index of keys wave*16 + kq*4
-                const uint2 lo = *reinterpret_cast<const uint2*>(&Vt[ch * PF_VS + p0]);
+                const uint2 lo = v_frag_tr(Vs, wave * DT + dt, kq, l15);  // keys wave*16 + kq*4 .. +4 of channel dt*16 + l15
                 const h8 bv = __builtin_bit_cast(h8, make_uint4(lo.x, lo.y, 0u, 0u));
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, bv, o[dt], 0, 0, 0);
             }
