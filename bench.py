@@ -177,6 +177,11 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # one node by contract: keep both control planes (gloo here, the RCCL bootstrap inside libpplhip) on the loopback
+        # interface so that neither depends on the container's hostname resolving or on an external NIC
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL P2P setup)
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     P = load_pplhip()
