@@ -816,8 +816,10 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
             static const int env_minkt = getenv("PPLHIP_GEMM_MINKT") ? atoi(getenv("PPLHIP_GEMM_MINKT")) : 0;
             const int target = M <= 64 ? 768 : 512;
             splits = (int)((target + tiles - 1) / tiles);
-            if (splits > 8) splits = 8;
-            const int min_kt = env_minkt ? env_minkt : ((M <= 64 || tiles < 64) ? 16 : 28);
+            const int cap = (M <= 64 || tiles <= 32) ? 8 : 4;  // (M = 128..256 sweeps: more than 4 slabs never paid)
+            if (splits > cap) splits = cap;
+            if (M > 64 && tiles >= 192) splits = 1;             // three quarters of the CUs busy already: a slab costs more
+            const int min_kt = env_minkt ? env_minkt : ((M <= 64 || tiles <= 64) ? 16 : 28);
             if (splits > kt_all / min_kt) splits = kt_all / min_kt > 0 ? kt_all / min_kt : 1;
             if (forced_split > 0) splits = forced_split;
             while (splits > 1 && (size_t)splits * M * N * sizeof(float) > ws_bytes) --splits;
