@@ -496,8 +496,8 @@ __global__ __launch_bounds__(WL == 5 ? 512 : 256) void gemm_dma_kernel(const uin
 //   (activations are tiny and L1/L2 resident); up to MT = 2 row tiles of 16 activations reuse each weight fragment.
 // ---------------------------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------------------------
-// W8A16, large M (prefill steps, M >= 4096): 256 x 256 x 64 block tile, 8 waves as 4 (n) x 2 (m), wave tile
-// 64 (n) x 128 (m) = 4 x 8 MFMA tiles.  Same DMA / int8-in-LDS / swizzle scheme as the 128 x 128 kernel, but per MFMA it
+// W8A16, large M (prefill steps, M >= 4096): 256 x 256 x 64 block tile, 8 waves as 8 (n) x 1 (m), wave tile
+// 32 (n) x 256 (m) = 2 x 16 MFMA tiles (each weight fragment is converted once and feeds 16 MFMAs; +2.5 % over 4 x 2).  Same DMA / int8-in-LDS / swizzle scheme as the 128 x 128 kernel, but per MFMA it
 // reads ~40 % fewer LDS bytes and converts half as many weight fragments, and each activation / weight byte fetched
 // from L2 feeds twice the flops.  One block per CU (3-stage ring = 144 KiB LDS), prefetch distance 2.
 // ---------------------------------------------------------------------------------------------------------------
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(512) void gemm_w8_dma256_kernel(const uint16_t* __r
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
-    const int wn = wave >> 1, wm = wave & 1;
+    const int wn = wave, wm = 0;  // 8 (n) x 1 (m): wave tile 32 (n) x 256 (m); every weight fragment is converted by one wave only
 
     const uint16_t* xsrc[4];
     const int8_t* wsrc[2];
@@ -549,11 +549,11 @@ __global__ __launch_bounds__(512) void gemm_w8_dma256_kernel(const uint16_t* __r
         for (int j = 0; j < 2; ++j) glds16(wsrc[j] + k0, wdst + stage * (H_BN * G_BK) + j * 8192);
     };
 
-    f4 acc[4][8];
+    f4 acc[2][16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 16; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
     const int ktiles = K / G_BK;
     issue(0, 0);
@@ -568,19 +568,19 @@ __global__ __launch_bounds__(512) void gemm_w8_dma256_kernel(const uint16_t* __r
         const int8_t* wq = Wq0 + st * (H_BN * G_BK);
         st = st == H_ST - 1 ? 0 : st + 1;
         stn = stn == H_ST - 1 ? 0 : stn + 1;
-        uint4 wraw[4];
+        uint4 wraw[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = wn * 64 + i * 16 + l15;
+        for (int i = 0; i < 2; ++i) {
+            const int row = wn * 32 + i * 16 + l15;
             wraw[i] = *reinterpret_cast<const uint4*>(&wq[row * G_BK + (kq ^ w_swz(row)) * 16]);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            h8 a[4];
+            h8 a[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = cvt_i8x8_f16(ks == 0 ? make_uint2(wraw[i].x, wraw[i].y) : make_uint2(wraw[i].z, wraw[i].w));
+            for (int i = 0; i < 2; ++i) a[i] = cvt_i8x8_f16(ks == 0 ? make_uint2(wraw[i].x, wraw[i].y) : make_uint2(wraw[i].z, wraw[i].w));
 #pragma unroll
-            for (int jh = 0; jh < 2; ++jh) {
+            for (int jh = 0; jh < 4; ++jh) {
                 h8 bfr[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(512) void gemm_w8_dma256_kernel(const uint16_t* __r
                     bfr[j] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&xs[row * G_BK + g_swz(row, ks * 4 + kq) * 8]));
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][jh * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], bfr[j], acc[i][jh * 4 + j], 0, 0, 0);
@@ -597,12 +597,12 @@ __global__ __launch_bounds__(512) void gemm_w8_dma256_kernel(const uint16_t* __r
     }
 
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wn * 64 + i * 16 + kq * 4;
+    for (int i = 0; i < 2; ++i) {
+        const int n = n0 + wn * 32 + i * 16 + kq * 4;
         if (n >= N) continue;
         const h4 sh = __builtin_bit_cast(h4, *reinterpret_cast<const uint2*>(scale + n));
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 16; ++j) {
             const int64_t m = m0 + wm * 128 + j * 16 + l15;
             if (m >= M) continue;
             store4<EPI>(yv, ldy, m, n, acc[i][j][0] * (float)sh[0], acc[i][j][1] * (float)sh[1], acc[i][j][2] * (float)sh[2],

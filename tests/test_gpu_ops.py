@@ -86,7 +86,8 @@ def test_rmsnorm(hidden, skip):
 
 @pytest.mark.parametrize("wq", [0, 8, 4])
 @pytest.mark.parametrize("M,N,K", [(1, 128, 128), (5, 384, 256), (130, 320, 128), (64, 512, 1376), (257, 1024, 4096),
-                                   (33, 1024, 704), (2100, 1284, 512), (100, 384, 4096), (200, 260, 2048), (1024, 1536, 1024)])
+                                   (33, 1024, 704), (2100, 1284, 512), (100, 384, 4096), (200, 260, 2048), (1024, 1536, 1024),
+                                   (4100, 1092, 256)])   # M >= 4096: the 256 x 256 tile kernel (prefill steps)
 def test_linear(wq, M, N, K):
     m = load_pplhip()
     if wq == 4 and K % 128:
