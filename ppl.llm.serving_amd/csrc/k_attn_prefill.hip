@@ -296,8 +296,8 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
                 for (int g = 0; g < RG; ++g)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        pa[g][r] = (_Float16)sacc[g][2 * s2][r];
-                        pa[g][4 + r] = (_Float16)sacc[g][2 * s2 + 1][r];
+                        pa[g][r] = to_h(sacc[g][2 * s2][r]);
+                        pa[g][4 + r] = to_h(sacc[g][2 * s2 + 1][r]);
                     }
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(PF_THREADS) void attn_decode_gqa_kernel(const uint1
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[dt][r] *= ar[r];
             // P.V over this wave's 16 keys: k-slots 0..3 = keys kq*4 + r, k-slots 4..7 unused (zero)
-            h8 pa = {(_Float16)sacc[0], (_Float16)sacc[1], (_Float16)sacc[2], (_Float16)sacc[3], (_Float16)0.f, (_Float16)0.f,
+            h8 pa = {to_h(sacc[0]), to_h(sacc[1]), to_h(sacc[2]), to_h(sacc[3]), (_Float16)0.f, (_Float16)0.f,
                      (_Float16)0.f, (_Float16)0.f};
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {

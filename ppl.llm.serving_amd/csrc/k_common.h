@@ -25,8 +25,18 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 __device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
-__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
-__device__ __forceinline__ float round_h(float f) { return (float)(_Float16)f; }
+// fp32 -> fp16 of a COMPUTED value: the empty asm pins the fp32 value in a register first.  Without it hipcc folds a preceding
+// fp32 multiply and the conversion into v_fma_mixlo_f16, which rounds the exact product once to fp16 -- not the same result as
+// v_mul_f32 + v_cvt_f16_f32 (fp32 rounding, then fp16 rounding: the oracle's arithmetic) when the fp32 rounding lands on an fp16
+// tie -- and it picks either form PER ELEMENT: in the GEMM epilogue 7 of the 8 row groups of a tile got the fused form for two of
+// their four columns and the 8th did not, so an output row depended on where its input row sat in the batch
+// (profiles/probes/gemm_position_probe*.py; caught by the permutation test of tests/test_gpu_properties.py).
+__device__ __forceinline__ _Float16 to_h(float f) {
+    asm("" : "+v"(f));
+    return (_Float16)f;
+}
+__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, to_h(f)); }
+__device__ __forceinline__ float round_h(float f) { return (float)to_h(f); }
 
 // 16-byte vector of 8 halfs <-> floats
 // 8 int8 -> 8 fp16, exact: x ^ 0x80 is the biased byte u = x + 128; v_perm puts it under the fp16 exponent 0x64
@@ -49,7 +59,7 @@ __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
 __device__ __forceinline__ uint4 pack8(const float* f) {
     h8 h;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) h[i] = (_Float16)f[i];
+    for (int i = 0; i < 8; ++i) h[i] = to_h(f[i]);
     return __builtin_bit_cast(uint4, h);
 }
 

@@ -21,7 +21,7 @@ __device__ __forceinline__ void store_group8(const KvAddr& kv, int kvsel, int he
         float mx = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fabsf(x[i]));
-        const _Float16 sh = (_Float16)(mx / 127.0f);
+        const _Float16 sh = to_h(mx / 127.0f);
         const float sf = (float)sh;
         const float inv = sf > 0.f ? __fdiv_rn(1.0f, sf) : 0.f;  // one correctly rounded reciprocal per group
         uint32_t lo = 0, hi = 0;
