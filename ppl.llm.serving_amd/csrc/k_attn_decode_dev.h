@@ -86,12 +86,12 @@ __device__ __forceinline__ void attn_decode_body(const uint16_t* __restrict__ qk
             const int64_t tok = t0 + u * TPW + g;
             valid[u] = tok < tend;
             const int64_t slot = kv_slot(kv, cache_indices, max_pages, b, valid[u] ? tok : tbeg);
-            kraw[u] = *reinterpret_cast<const uint4*>(kbase + slot * row_bytes);
-            vraw[u] = *reinterpret_cast<const uint4*>(vbase + slot * row_bytes);
+            kraw[u] = kv_stream_load(reinterpret_cast<const uint4*>(kbase + slot * row_bytes));
+            vraw[u] = kv_stream_load(reinterpret_cast<const uint4*>(vbase + slot * row_bytes));
             if constexpr (QBIT == 8) {
                 if constexpr (C::NG == 2) {
-                    ksc[u] = *reinterpret_cast<const uint32_t*>(ksbase + slot * kv.ssN);
-                    vsc[u] = *reinterpret_cast<const uint32_t*>(vsbase + slot * kv.ssN);
+                    ksc[u] = kv_stream_load(reinterpret_cast<const uint32_t*>(ksbase + slot * kv.ssN));
+                    vsc[u] = kv_stream_load(reinterpret_cast<const uint32_t*>(vsbase + slot * kv.ssN));
                 } else {
                     ksc[u] = ksbase[slot * kv.ssN];
                     vsc[u] = vsbase[slot * kv.ssN];

@@ -436,11 +436,11 @@ __global__ __launch_bounds__(PF_THREADS) void attn_decode_gqa_kernel(const uint1
                     int64_t key = key0 + 2 * kp + e;
                     if (key >= tend) key = tend - 1;
                     const int64_t slot = MODE == 0 ? slot0 + key : kv_slot(kv, cache_indices, max_pages, b, key);
-                    kraw[p][it][e] = *reinterpret_cast<const uint4*>(kbase + (slot * kv.sN + c * CH) * ELT);
-                    vraw[p][it][e] = *reinterpret_cast<const uint4*>(vbase + (slot * kv.sN + c * CH) * ELT);
+                    kraw[p][it][e] = kv_stream_load(reinterpret_cast<const uint4*>(kbase + (slot * kv.sN + c * CH) * ELT));
+                    vraw[p][it][e] = kv_stream_load(reinterpret_cast<const uint4*>(vbase + (slot * kv.sN + c * CH) * ELT));
                     if constexpr (QBIT == 8) {
-                        ksc[p][it][e] = *reinterpret_cast<const uint32_t*>(ksbase + slot * kv.ssN + c * 2);
-                        vsc[p][it][e] = *reinterpret_cast<const uint32_t*>(vsbase + slot * kv.ssN + c * 2);
+                        ksc[p][it][e] = kv_stream_load(reinterpret_cast<const uint32_t*>(ksbase + slot * kv.ssN + c * 2));
+                        vsc[p][it][e] = kv_stream_load(reinterpret_cast<const uint32_t*>(vsbase + slot * kv.ssN + c * 2));
                     }
                 }
             }

@@ -63,6 +63,28 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
     return __builtin_bit_cast(uint4, h);
 }
 
+// Decode attention reads every K/V row exactly once per step: non-temporal loads (compile-time switch PPLHIP_KV_NT) stream them
+// past the caches instead of through them -- measured +5..9 % (batch 1024 kv 512: 5.92 -> 6.23 TB/s, kv 1024: 6.24 -> 6.70 TB/s,
+// profiles/attn_microbench.py; MI355X_MICROARCH.md quotes 6.4 TB/s default policy vs 6.5-6.8 nt for a streaming read)
+#ifndef PPLHIP_KV_NT
+#define PPLHIP_KV_NT 1
+#endif
+typedef uint32_t kv_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 kv_stream_load(const uint4* p) {
+#if PPLHIP_KV_NT
+    return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const kv_u32x4*>(p)));
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ uint32_t kv_stream_load(const uint32_t* p) {
+#if PPLHIP_KV_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 // KV slab addressing (src/engine/llm_engine.cc:118-169): element strides of (layer, k/v, head, token)
 // for the four cache layouts; `d` is the innermost extent (head_dim, or head_dim/group for scales).
 struct KvStrides {
