@@ -75,6 +75,8 @@ hipError_t launch_attn_decode(hipStream_t s, const uint16_t* qkv, const KvAddr& 
                               int64_t max_pages, int64_t nb, int H, int Hkv, int D, int64_t max_kv_len, int split,
                               int threads, float* workspace, uint16_t* out) {
     if (nb == 0) return hipSuccess;
+    static const int forced_tpb = getenv("PPLHIP_ATTN_TPB") ? atoi(getenv("PPLHIP_ATTN_TPB")) : 0;  // tuning only
+    if (forced_tpb) threads = forced_tpb;
     if (threads < 64 || threads > 64 * DEC_MAX_WAVES || threads % 64) return hipErrorInvalidValue;
     if (threads < D) threads = D;  // the final merge uses one thread per channel
     if (split < 1) split = 1;
