@@ -519,7 +519,7 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
             splits = (int)((target + tiles - 1) / tiles);
             const int cap = (M <= 64 || tiles <= 32) ? 8 : 4;  // (M = 128..256 sweeps: more than 4 slabs never paid)
             if (splits > cap) splits = cap;
-            if (M > 64 && tiles >= 192) splits = 1;             // three quarters of the CUs busy already: a slab costs more
+            if (M > 64 && tiles >= 160) splits = 1;             // most CUs busy already: a slab costs more (176 tiles, 7B/TP8 w13: 36 vs 42 us)
             const int min_kt = env_minkt ? env_minkt : ((M <= 64 || tiles <= 64) ? 16 : 28);
             if (splits > kt_all / min_kt) splits = kt_all / min_kt > 0 ? kt_all / min_kt : 1;
             if (forced_split > 0) splits = forced_split;
