@@ -81,10 +81,13 @@ hipError_t launch_fused_attn_gemm(hipStream_t s, const uint16_t* qkv, const KvAd
     if (P > 1 && (P & 1) == 0) --P;
     static const int wl = getenv("PPLHIP_FUSED_WL") ? atoi(getenv("PPLHIP_FUSED_WL")) : 1;  // 5: producer / consumer waves
     const dim3 grid((unsigned)(n_attn + n_gemm)), block(wl == 5 ? 512 : 256);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     static const int st = getenv("PPLHIP_FUSED_STAGES") ? atoi(getenv("PPLHIP_FUSED_STAGES")) : 2;  // GEMM role's ring depth
 #define FUSED1(QB, E, ST, WL)                                                                                                     \
     do {                                                                                                                          \
-        static bool attr = false;                                                                                                 \
+        static bool attr_dev[64] = {false};  /* the attribute is per device */                                                   \
+        bool& attr = attr_dev[dev & 63];                                                                                          \
         constexpr int lds = gemm_dma_lds_bytes<8, ST>();                                                                          \
         if (!attr) { (void)hipFuncSetAttribute((const void*)fused_attn_gemm_kernel<QB, E, ST, WL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; } \
         hipLaunchKernelGGL((fused_attn_gemm_kernel<QB, E, ST, WL>), grid, block, lds, s, a, g, n_attn, n_gemm, P);                \

@@ -477,7 +477,12 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         const int nt2 = (N + H_BN - 1) / H_BN, mt2 = (int)((M + H_BM - 1) / H_BM);
         const size_t lds = (size_t)H_ST * (H_BM * G_BK * 2 + H_BN * G_BK);
         dim3 g256((unsigned)((nt2 + 7) / 8 * 8 * mt2));
-        static bool attr_set = false;
+        // (the attribute belongs to the function ON THE CURRENT DEVICE: one flag per device, or the other ranks of a single-process
+        // tensor-parallel run would launch without it)
+        static bool attr_dev[64] = {false};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        bool& attr_set = attr_dev[dev & 63];
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)gemm_w8_dma256_kernel<EPI_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute((const void*)gemm_w8_dma256_kernel<EPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -93,7 +93,7 @@ __device__ __forceinline__ void gemm_dma_body(const uint16_t* __restrict__ x, co
     constexpr int NT = 256;                                // threads that move tile pieces (WL 5: the 4 producer waves)
     constexpr int X_DMA = G_BM * G_BK * 2 / (NT * 16);     // DMA instructions per wave per tile for X (4 or 2)
     constexpr int W_DMA = W_STAGE / (NT * 16);             // ... for W (2 int8, 4 fp16, 1 int4)
-    constexpr int SC_BYTES = WQ == 4 ? W4_MAXG * G_BN * 2 : 0;  // W4: group scales of this block's rows, [group][row]
+    // (W4: W4_MAXG * G_BN * 2 more bytes for the group scales of this block's rows, [group][row])
     // smem: G_ST * (G_BM * G_BK * 2 + W_STAGE) + SC_BYTES bytes (per stage: X 16 KiB + W), 16-byte aligned, provided by the caller
     uint16_t* const Xs0 = reinterpret_cast<uint16_t*>(smem);
     char* const Wq0 = smem + G_ST * G_BM * G_BK * 2;
