@@ -346,6 +346,9 @@ def simulate(sc):
                 t = rows[row]
                 rows[row] = None
                 erased.add(fid)
+                # deviation from the reference (it leaves the flag alone): rows shift, so the next Execute must re-upload
+                # the page table / sampler and penalty rows even when the removal came from a cancel on a quiet step
+                changed = True
                 if mode == 0:
                     idx.release(t["cache_index"], t["total_len"] - 1)
                 elif prefix:

@@ -653,8 +653,12 @@ REF_API void ref_sample(const float* logits, const float* temperatures, const fl
         for (int i = 0; i < vocab; ++i) den += exp((double)(row[i] * invt - mx));
         const float lse = mx + (float)log(den);
         int tok = am;
-        if (top_k > 1) {
-            const int k = top_k < vocab ? top_k : vocab;
+        if (top_k != 1) {
+            /* top_k <= 0: top-p over the whole vocabulary (probabilities = softmax over ALL logits), candidates capped
+             * at 1024; top_k > 1024 is clamped to 1024 */
+            const int full = top_k <= 0;
+            int k = full ? 1024 : (top_k < 1024 ? top_k : 1024);
+            if (k > vocab) k = vocab;
             int* idx = (int*)malloc(sizeof(int) * k);
             float* val = (float*)malloc(sizeof(float) * k);
             int n = 0;
@@ -669,7 +673,8 @@ REF_API void ref_sample(const float* logits, const float* temperatures, const fl
             }
             const float tp = top_p ? top_p[b] : default_top_p;
             double tot = 0;
-            for (int i = 0; i < n; ++i) tot += exp((double)(val[i] - mx));
+            if (full) tot = den;
+            else for (int i = 0; i < n; ++i) tot += exp((double)(val[i] - mx));
             double cum = 0; int keep = 0;
             for (int i = 0; i < n; ++i) { cum += exp((double)(val[i] - mx)) / tot; keep = i + 1; if (cum >= (double)tp) break; }
             double ktot = 0;

@@ -65,6 +65,9 @@ hipError_t launch_sample_greedy(hipStream_t s, const float* logits, const float*
 // top-k / top-p: candidates = k largest x (ties: lower index first) found by k block-wide selection passes
 // (the row stays L2-resident); p = softmax over candidates; keep the shortest prefix with cumulative p >= top_p
 // (at least one); pick the first candidate whose cumulative mass exceeds rand * kept mass.
+// top_k <= 0 (the usual "pure top-p" request): the candidates are the whole vocabulary -- p is the softmax over ALL
+// logits -- and the selection passes stop as soon as the nucleus is complete (or at TOPK_MAX candidates).
+// top_k > TOPK_MAX is clamped to TOPK_MAX.  A per-request parameter never fails the batch.
 constexpr int TOPK_MAX = 1024;
 __global__ __launch_bounds__(256) void sample_topk_topp_kernel(const float* __restrict__ logits,
                                                                const float* __restrict__ temperatures,
@@ -80,9 +83,12 @@ __global__ __launch_bounds__(256) void sample_topk_topp_kernel(const float* __re
     const float* row = logits + (int64_t)b * stride;
     const float t = (temperatures && temperatures[b] > 0.f) ? temperatures[b] : 1.0f;
     const float invt = 1.0f / t;
-    const int k = top_k < vocab ? top_k : vocab;
-    float pv = INFINITY;
-    int pi = -1;
+    const bool full = top_k <= 0;
+    int k = full ? TOPK_MAX : (top_k < TOPK_MAX ? top_k : TOPK_MAX);
+    if (k > vocab) k = vocab;
+    const float tp = top_p ? top_p[b] : default_top_p;
+    float pv = INFINITY, mx = 0.f, se = 0.f, cum = 0.f;
+    int pi = -1, n = 0;
     for (int it = 0; it < k; ++it) {
         ArgMax am{-INFINITY, 0x7fffffff};
         for (int i = threadIdx.x; i < vocab; i += 256) {
@@ -96,22 +102,29 @@ __global__ __launch_bounds__(256) void sample_topk_topp_kernel(const float* __re
         for (int w = 1; w < 4; ++w) am = am_better(am, ArgMax{sv[w], si[w]});
         if (threadIdx.x == 0) { cv[it] = am.v; ci[it] = am.i; }
         pv = am.v; pi = am.i;
+        n = it + 1;
+        if (it == 0) {  // the row maximum is known: total mass of the row
+            mx = am.v;
+            float part = 0.f;
+            for (int i = threadIdx.x; i < vocab; i += 256) part += __expf(row[i] * invt - mx);
+            part = wave_sum(part);
+            if ((threadIdx.x & 63) == 0) ss[threadIdx.x >> 6] = part;
+            __syncthreads();
+            se = ss[0] + ss[1] + ss[2] + ss[3];
+        }
         __syncthreads();
+        if (full) {     // (block-uniform: every thread adds the same broadcast values)
+            cum += __expf(am.v - mx);
+            if (cum >= tp * se) break;
+        }
     }
-    const float mx = cv[0];
-    float se = 0.f;
-    for (int i = threadIdx.x; i < vocab; i += 256) se += __expf(row[i] * invt - mx);
-    se = wave_sum(se);
-    if ((threadIdx.x & 63) == 0) ss[threadIdx.x >> 6] = se;
-    __syncthreads();
     if (threadIdx.x == 0) {
-        se = ss[0] + ss[1] + ss[2] + ss[3];
-        const float tp = top_p ? top_p[b] : default_top_p;
         float tot = 0.f;
-        for (int i = 0; i < k; ++i) tot += expf(cv[i] - mx);
-        float cum = 0.f;
+        if (full) tot = se;
+        else for (int i = 0; i < n; ++i) tot += expf(cv[i] - mx);
+        float c1 = 0.f;
         int keep = 0;
-        for (int i = 0; i < k; ++i) { cum += expf(cv[i] - mx) / tot; keep = i + 1; if (cum >= tp) break; }
+        for (int i = 0; i < n; ++i) { c1 += expf(cv[i] - mx) / tot; keep = i + 1; if (c1 >= tp) break; }
         float ktot = 0.f;
         for (int i = 0; i < keep; ++i) ktot += expf(cv[i] - mx);
         const float target = rnd[b] * ktot;
@@ -129,14 +142,15 @@ hipError_t launch_sample_topk_topp(hipStream_t s, const float* logits, const flo
                                    const float* rnd, int batch, int vocab, int stride, int top_k, float default_top_p,
                                    void*, int32_t* out_tok, float* out_logprob) {
     if (batch == 0) return hipSuccess;
-    if (top_k > TOPK_MAX) return hipErrorInvalidValue;
     hipLaunchKernelGGL(sample_topk_topp_kernel, dim3(batch), dim3(256), 0, s, logits, temperatures, top_p, rnd, vocab,
                        stride, top_k, default_top_p, out_tok, out_logprob);
     return hipGetLastError();
 }
 
 // penalty: count map row batch_slots[b] (uint16, saturating) counts every token the request has fed the model;
-// cleared when start_pos[b] == 0.  For counted tokens: x = x > 0 ? x/rep : x*rep; x -= presence; x -= freq*count;
+// cleared on a request's first step: start_pos[b] == 0, or row b >= decoding_batches (a prefill row -- a prompt is always
+// prefilled in ONE step, so this also catches a prefix-cache hit that starts at start_pos = hit > 0 in a reused batch slot;
+// the cached prompt tokens themselves are never fed and stay uncounted, as in the reference).  For counted tokens: x = x > 0 ? x/rep : x*rep; x -= presence; x -= freq*count;
 // finally every logit is divided by the temperature.
 __global__ __launch_bounds__(256) void penalty_kernel(float* __restrict__ logits, const float* __restrict__ temperatures,
                                                       const float* __restrict__ rep, const float* __restrict__ presence,
@@ -145,10 +159,10 @@ __global__ __launch_bounds__(256) void penalty_kernel(float* __restrict__ logits
                                                       const int64_t* __restrict__ token_inputs,
                                                       const int64_t* __restrict__ seq_starts,
                                                       const int64_t* __restrict__ start_pos, int vocab, int stride,
-                                                      uint16_t* __restrict__ count_map) {
+                                                      int decoding_batches, uint16_t* __restrict__ count_map) {
     const int b = blockIdx.x;
     uint16_t* cm = count_map + batch_slots[b] * (int64_t)vocab;
-    if (start_pos[b] == 0) {
+    if (start_pos[b] == 0 || b >= decoding_batches) {
         for (int v = threadIdx.x; v < vocab; v += 256) cm[v] = 0;
     }
     __syncthreads();
@@ -188,11 +202,11 @@ __global__ __launch_bounds__(256) void penalty_kernel(float* __restrict__ logits
 hipError_t launch_penalty(hipStream_t s, float* logits, const float* temperatures, const float* rep,
                           const float* presence, const float* frequency, const int64_t* batch_slots,
                           const int64_t* token_inputs, const int64_t* seq_starts, const int64_t* start_pos, int batch,
-                          int vocab, int stride, uint16_t* count_map) {
+                          int vocab, int stride, int decoding_batches, uint16_t* count_map) {
     if (batch == 0) return hipSuccess;
     if (vocab & 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL(penalty_kernel, dim3(batch), dim3(256), 0, s, logits, temperatures, rep, presence, frequency,
-                       batch_slots, token_inputs, seq_starts, start_pos, vocab, stride, count_map);
+                       batch_slots, token_inputs, seq_starts, start_pos, vocab, stride, decoding_batches, count_map);
     return hipGetLastError();
 }
 

@@ -76,7 +76,7 @@ hipError_t launch_sample_topk_topp(hipStream_t s, const float* logits, const flo
 hipError_t launch_penalty(hipStream_t s, float* logits, const float* temperatures, const float* rep,
                           const float* presence, const float* frequency, const int64_t* batch_slots,
                           const int64_t* token_inputs, const int64_t* seq_starts, const int64_t* start_pos, int batch,
-                          int vocab, int stride, uint16_t* count_map);
+                          int vocab, int stride, int decoding_batches, uint16_t* count_map);
 
 // ---- synth.hip --------------------------------------------------------------------------------
 // kinds as in oracle/llama_ref.c: 0 fp16 uniform(-amp,amp), 1 int8, 2 packed int4 (n bytes), 3 scale, 4 norm

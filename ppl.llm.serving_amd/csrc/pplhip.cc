@@ -1127,12 +1127,12 @@ int pplhip_sample(pplhip_ctx* c, const float* logits_device, const pplhip_sample
     for (int i = 0; i < B; ++i) R.h_rand[i] = (float)rand() / (float)RAND_MAX;
     if (a->default_top_k == 1) {
         HIPCK(c, 0, launch_sample_greedy(s, logits_device, temp_opt, B, a->vocab_size, a->batch_stride, R.d_tokout, R.d_lp));
-    } else if (a->default_top_k > 1) {
+    } else {
+        // top_k <= 0: top-p over the whole vocabulary; top_k > 1024 is clamped (k_sample.hip).  default_top_k is the FIRST
+        // row's client-supplied value: it must never turn into a batch-wide Execute failure.
         HIPCK(c, 0, hipMemcpyAsync(R.d_rand, R.h_rand, B * 4, hipMemcpyHostToDevice, s));
         HIPCK(c, 0, launch_sample_topk_topp(s, logits_device, temp_opt, topp_opt, R.d_rand, B, a->vocab_size, a->batch_stride,
                                             a->default_top_k, a->default_top_p, nullptr, R.d_tokout, R.d_lp));
-    } else {
-        return fail(c, 0, PPLHIP_UNSUPPORTED, "top_k <= 0 (pure top-p sampling) is not supported");
     }
     HIPCK(c, 0, hipMemcpyAsync(output_host, R.d_tokout, B * 4, hipMemcpyDeviceToHost, s));
     HIPCK(c, 0, hipMemcpyAsync(logprob_host, R.d_lp, B * 4, hipMemcpyDeviceToHost, s));
@@ -1157,7 +1157,7 @@ int pplhip_penalty(pplhip_ctx* c, float* logits_device, const pplhip_penalty_arg
     }
     HIPCK(c, 0, launch_penalty(s, logits_device, R.d_ptemp, R.d_rep, a->presence_penalties ? R.d_pres : nullptr,
                                a->frequency_penalties ? R.d_freq : nullptr, R.d_slots, R.d_tok, R.d_seq, R.d_sp, B,
-                               a->vocab_size, c->d.vocab_size, R.count_map));
+                               a->vocab_size, c->d.vocab_size, (int)R.decoding_batches, R.count_map));
     return 0;
 }
 

@@ -83,6 +83,13 @@ RetCode LLMGenerator::Init() {
     if (rc != RC_SUCCESS) { LOG(ERROR) << "CheckParameters failed."; return rc; }
     rc = llm_engine_.Init(&worker_profiler_->step_counter);
     if (rc != RC_SUCCESS) { LOG(ERROR) << "LLM Engine Init failed."; return rc; }
+    // the rope table (and pplhip_set_inputs' range check) ends at max_position: a request may never grow past it, or one
+    // long request would fail Execute for the whole running batch.  Clamp per request at admission instead.
+    if (model_config_.max_position > 0 && generator_config_.max_total_tokens_per_request > model_config_.max_position) {
+        LOG(WARNING) << "max_total_tokens_per_request [" << generator_config_.max_total_tokens_per_request
+                     << "] > model max_position [" << model_config_.max_position << "]. use [" << model_config_.max_position << "]";
+        generator_config_.max_total_tokens_per_request = model_config_.max_position;
+    }
     rc = decoder_thread_pool_.Init(DECODER_THREAD_NUM);
     if (rc != RC_SUCCESS) { LOG(ERROR) << "Init decoder thread pool error"; return RC_OTHER_ERROR; }
     generate_thread_active_.store(true, std::memory_order_release);
@@ -407,6 +414,10 @@ void LLMGenerator::DeleteTasks(ModelInput* in) {
         while (row < tid_list_.size() && !(tid_list_[row] && tid_list_[row]->tid == info.id)) ++row;
         if (row == tid_list_.size()) continue;
         tid_list_[row] = nullptr;
+        // the batch rows shift: the device page table, the penalty slots and the sampler's per-row parameters must be
+        // re-uploaded by the next Execute even when nothing finished in the worker and nothing new was admitted (a
+        // cancel from the connection on an otherwise quiet step; the reference leaves the flag untouched here)
+        req_list_changed_ = true;
         if (model_config_.cache_mode == 0) {
             idx_mgr_.Free(t.cache_index, (uint64_t)t.total_len - 1);
         } else if (generator_config_.enable_prefix_cache) {

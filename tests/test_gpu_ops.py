@@ -334,6 +334,34 @@ def test_sampler_greedy_and_topk():
     ctx.close()
 
 
+@pytest.mark.parametrize("top_k,top_p", [(0, 0.8), (-3, 0.25), (5000, 0.97)])
+def test_sampler_pure_top_p_and_clamped_top_k(top_k, top_p):
+    """per-request values a client may send (grpc default top_k = 0 = pure top-p; top_k above the 1024-candidate cap):
+    never an error; top_k <= 0 samples from the nucleus of the WHOLE-vocabulary softmax, top_k > 1024 is clamped.
+    The device draws its random numbers from libc rand() (post_processor.cc:179-183): replay that stream for the oracle."""
+    m = load_pplhip()
+    rng = np.random.RandomState(21)
+    B, V = 17, 32000
+    logits = (rng.randn(B, V) * 3).astype(np.float32)
+    temps = (0.5 + rng.rand(B)).astype(np.float32)
+    desc = m.make_desc(hidden_dim=128, intermediate_dim=128, num_layers=1, num_heads=4, num_kv_heads=4, vocab_size=V)
+    ctx = m.Context(desc, max_running_batch=64, max_tokens_per_step=64)
+    d = dev(logits)
+    tok, lp = ctx.sample(B, top_k=top_k, top_p=top_p, temperatures=temps, logits_ptr=d.data_ptr())
+    full = top_k <= 0
+    k = 1024 if full else min(top_k, 1024)
+    for b in range(B):
+        x = logits[b] / temps[b]
+        order = np.argsort(-x, kind="stable")[:k]
+        e = np.exp((x[order] - x.max()).astype(np.float64))
+        tot = np.exp((x - x.max()).astype(np.float64)).sum() if full else e.sum()
+        keep = int(np.searchsorted(np.cumsum(e / tot), top_p) + 1)
+        assert tok[b] in order[:keep + 1]          # (+1: fp32 vs fp64 cumulative sums may disagree on the boundary candidate)
+        lse = np.log(np.exp((x - x.max()).astype(np.float64)).sum()) + x.max()
+        assert abs(lp[b] - (x[tok[b]] - lse)) < 1e-3
+    ctx.close()
+
+
 @pytest.mark.parametrize("wq", [0, 8, 4])
 @pytest.mark.parametrize("M,inter,K", [(3, 64, 128), (40, 192, 256), (300, 1376, 512)])
 def test_linear_swiglu_fused(wq, M, inter, K):

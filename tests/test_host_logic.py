@@ -200,3 +200,25 @@ def test_cpp_cancel_and_execute_failure(trace_bin):
     sc2["fail_at_run"] = 3
     steps, responses, failed = compare(trace_bin, sc2)
     assert sorted(failed) == [0, 1, 2, 3, 4, 5] and len(steps) == 4
+
+
+def test_cpp_cancel_on_a_quiet_step_marks_the_batch_changed(trace_bin):
+    """paged mode, three running requests, empty queue, one of them cancelled by the connection while nothing finishes
+    and nothing is admitted: the rows shift, so the NEXT step must carry req_list_changed = 1 and a repacked page list
+    (otherwise the device keeps the old rows' page table and the survivors read / write another request's pages)."""
+    sc = {"model": {"cache_mode": 1, "page_size": 4, "vocab_size": 700}, "generator": {"max_running_batch": 8},
+          "kv_cache_max_tokens": 256,
+          "requests": [{"id": i, "tokens": [10 + i, 20 + i, 30 + i, 40 + i, 50 + i], "generation_length": 12, "early_stopping": False}
+                       for i in range(3)],
+          "cancel": [{"at_step": 3, "id": 0}]}
+    steps, responses, _ = compare(trace_bin, sc)
+    assert [s["req_list_changed"] for s in steps[:6]] == [1, 0, 0, 0, 1, 0]
+    before, after = steps[3], steps[4]
+    mp = before["max_pages"]
+    assert after["page_list"] == before["page_list"][mp:]                 # rows 1, 2 moved up with THEIR pages
+    assert len(responses[0]["tokens"]) == 4 and len(responses[1]["tokens"]) == 12 and len(responses[2]["tokens"]) == 12
+    # survivors' tokens equal an uncancelled run's
+    sc2 = dict(sc)
+    sc2.pop("cancel")
+    _, responses2, _ = compare(trace_bin, sc2)
+    assert responses[1] == responses2[1] and responses[2] == responses2[2]
