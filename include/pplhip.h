@@ -233,7 +233,7 @@ PPLHIP_API int pplhip_penalty(pplhip_ctx* ctx, float* logits_device, const pplhi
 
 /* kernel classes that are timed with HIP events when opts.enable_profiling != 0 */
 enum { PPLHIP_PROF_ATTN_DECODE = 0, PPLHIP_PROF_ATTN_PREFILL = 1, PPLHIP_PROF_GEMM = 2,
-       PPLHIP_PROF_RUN = 3, PPLHIP_PROF_FUSED = 4 /* decode attention + GEMM in one launch */, PPLHIP_PROF_COUNT = 5 };
+       PPLHIP_PROF_RUN = 3, PPLHIP_PROF_COUNT = 4 };
 
 /* clears the event log of this rank. */
 PPLHIP_API int pplhip_profile_reset(pplhip_ctx* ctx, int rank);
@@ -294,15 +294,6 @@ PPLHIP_API int pplhip_op_attention(void* stream, const void* qkv, const pplhip_k
                                    int64_t decoding_batches, int64_t max_seq_len, int64_t max_kv_len,
                                    int32_t num_heads, int32_t split_k, void* workspace, uint64_t workspace_bytes,
                                    void* out);
-
-/* ONE launch with two workgroup roles (k_fused.hip): decode attention (split 1) of B decode requests, and the W8A16 matmul
- * y[M,N] = x[M,K] . W[N,K]^T (swiglu != 0: W rows interleaved as in pplhip_op_linear_swiglu, y[M, N/2]) of an independent
- * set of rows.  Same results as pplhip_op_attention + pplhip_op_linear(_swiglu) without split-K.  head_dim 128, fp16 or
- * int8 KV, num_heads / kv_heads < 4, K % 64 == 0; anything else returns PPLHIP_INVALID_VALUE. */
-PPLHIP_API int pplhip_op_attention_linear(void* stream, const void* qkv, const pplhip_kv_view* kv, const int64_t* seq_starts,
-                                          const int64_t* start_pos, const int64_t* cache_indices, int64_t max_pages,
-                                          int64_t B, int32_t num_heads, void* attn_out, const void* x, const void* w,
-                                          const void* scale, int64_t M, int32_t N, int32_t K, void* y, int32_t swiglu);
 
 /* builds the fp32 cos/sin table [max_position, head_dim] (cos first half, sin second half per row). */
 PPLHIP_API int pplhip_build_rope_table(float* host_out, int32_t max_position, int32_t head_dim, float theta);

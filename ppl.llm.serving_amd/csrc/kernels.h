@@ -56,16 +56,6 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
 // dst row r = src row perm(r): r even -> r/2 (gate), r odd -> half + r/2 (up).  row_bytes % 4 == 0.
 hipError_t launch_interleave_rows(hipStream_t s, const void* src, void* dst, int rows, int64_t row_bytes);
 
-// ---- k_fused.hip ------------------------------------------------------------------------------
-// one launch with two workgroup roles: decode attention of `nb` requests (pointers offset to the first of them; split 1) and
-// the W8A16 tile GEMM y[M,N] = x . W^T of ANOTHER set of rows (fp16 output or fused SwiGLU).  Same results as the two launches
-// (PPLHIP_FUSED_WL=5 runs the attention role with 8 waves instead of 4: other rounding in the merge of the partial softmaxes).
-bool fused_attn_gemm_supported(int kv_quant_bit, int D, int H, int Hkv, int wq_bit, int K, int N);
-hipError_t launch_fused_attn_gemm(hipStream_t s, const uint16_t* qkv, const KvAddr& kv, int kv_quant_bit, const int64_t* seq_starts,
-                                  const int64_t* start_pos, const int64_t* cache_indices, int64_t max_pages, int64_t nb, int H,
-                                  int Hkv, uint16_t* attn_out, const uint16_t* x, const void* w, const uint16_t* scale, int64_t M,
-                                  int N, int K, void* y, int64_t ldy, bool swiglu);
-
 // ---- k_sample.hip -----------------------------------------------------------------------------
 hipError_t launch_sample_greedy(hipStream_t s, const float* logits, const float* temperatures, int batch, int vocab,
                                 int stride, int32_t* out_tok, float* out_logprob);

@@ -119,9 +119,6 @@ struct pplhip_ctx {
     // of 8 MB it hides are worth -- so it is used for steps that carry prefill tokens (T >= 2048: 16+ MB per
     // all-reduce, chunks of >= 1024 rows keep the GEMM tiles full), not for pure decode steps of <= 1024 rows.
     int64_t tp_overlap_min_tokens = 2048;
-    // PPLHIP_FUSED_DECODE=0 / PPLHIP_FUSED_MIN_BATCH: the role-fused schedule of pure-decode steps (run_decode_fused)
-    bool fused_decode = false;
-    int64_t fused_min_batch = 512;
     int H = 0, Hkv = 0, D = 0, inter = 0, vocab_local = 0;
     std::vector<Rank> ranks;
     std::string err;
@@ -355,8 +352,6 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
     const bool want_comm = tp > 1 || getenv("PPLHIP_FORCE_COMM") != nullptr;
     if (const char* e = getenv("PPLHIP_TP_OVERLAP")) c->tp_overlap = atoi(e) != 0;
     if (const char* e = getenv("PPLHIP_TP_OVERLAP_MIN_TOKENS")) c->tp_overlap_min_tokens = std::max(2, atoi(e));
-    if (const char* e = getenv("PPLHIP_FUSED_DECODE")) c->fused_decode = atoi(e) != 0;
-    if (const char* e = getenv("PPLHIP_FUSED_MIN_BATCH")) c->fused_min_batch = std::max(2, atoi(e));
     if (want_comm) {
         std::vector<ncclComm_t> comms(n);
         // PPLHIP_EMULATE_TP=1 (measurement only): this process holds n of the tp slices but the communicator spans only
@@ -858,135 +853,6 @@ static int chunk_allreduce(pplhip_ctx* c, int rank, uint16_t* buf, const Chunk& 
     return 0;
 }
 
-// ---- role-fused schedule of a pure-decode step (single device) ---------------------------------------------------
-// The step's requests are cut into two halves that run half a layer apart on ONE stream: while one half is in its
-// attention (HBM-bound), the other half is in its matmul chain wo -> w13 -> w2 -> wqkv(next layer) (MFMA-bound), and
-// each of those four GEMMs is launched TOGETHER with a slice of the other half's attention as one kernel with two
-// workgroup roles (k_fused.hip) -- the only form of co-execution of the two that the hardware dispatcher grants
-// (DESIGN.md "role-fused decode").  The slices are sized in proportion to the GEMMs' work so that both roles of a
-// launch end together.  Rows are independent in every kernel of the layer and the roles run the standard kernels'
-// bodies, so the logits equal those of the plain schedule whenever that one does not split K.
-static bool fused_decode_applies(pplhip_ctx* c, const Rank& R, int64_t nb_decode, int threads) {
-    const pplhip_model_desc& d = c->d;
-    if (!c->fused_decode || R.comm || nb_decode != R.B || R.T != R.B || R.B < c->fused_min_batch || threads != 256) return false;
-    if (decode_split(c, R.B, R.max_kv_len) != 1) return false;
-    for (const Layer& L : R.layers) {
-        const Linear* lin[4] = {&L.wqkv, &L.wo, &L.w13, &L.w2};
-        for (int i = 0; i < 4; ++i)
-            if (!fused_attn_gemm_supported(d.cache_quant_bit, c->D, c->H, c->Hkv, lin[i]->qbit, i == 3 ? lin[i]->Kp : lin[i]->K, lin[i]->N))
-                return false;
-    }
-    return true;
-}
-
-static int run_decode_fused(pplhip_ctx* c, int rank) {
-    Rank& R = c->ranks[rank];
-    const pplhip_model_desc& d = c->d;
-    hipStream_t s = R.stream;
-    const int hd = d.hidden_dim, H = c->H, Hkv = c->Hkv, D = c->D, nl = d.num_layers;
-    const int nqkv = (H + 2 * Hkv) * D;
-    const int64_t B = R.B;
-    int64_t m = (B / 2 + 127) / 128 * 128;  // whole 128-row GEMM tiles in the first half
-    if (m >= B) m = B / 2;
-    const Chunk hv[2] = {Chunk{0, m, 0, m, m}, Chunk{m, B - m, m, B - m, B - m}};
-    const int64_t ci_stride = d.cache_mode == 1 ? R.max_pages : 1;
-    ProfEvent ev;
-
-    struct Gemm { const uint16_t* x; const Linear* lin; int K; void* y; int64_t ldy; bool swiglu; };
-    enum { WO = 0, W13 = 1, W2 = 2, WQKV = 3 };
-    auto gemm_of = [&](int which, int l, const Chunk& k) -> Gemm {
-        Layer& L = R.layers[l];
-        switch (which) {
-            case WO:  return Gemm{R.att + k.t0 * (int64_t)H * D, &L.wo, L.wo.K, R.part + k.t0 * hd, hd, false};
-            case W13: return Gemm{R.xn + k.t0 * hd, &L.w13, L.w13.K, R.act + k.t0 * (int64_t)L.w2.Kp, L.w2.Kp, true};
-            case W2:  return Gemm{R.act + k.t0 * (int64_t)L.w2.Kp, &L.w2, L.w2.Kp, R.part2 + k.t0 * hd, hd, false};
-            default:  return Gemm{R.xn + k.t0 * hd, &L.wqkv, L.wqkv.K, R.qkv + k.t0 * nqkv, L.wqkv.N, false};
-        }
-    };
-    auto plain_gemm = [&](const Gemm& g, int64_t M) -> int {
-        prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-        HIPCK(c, rank, launch_linear(s, g.x, g.lin->w, g.lin->scale, g.lin->qbit, g.lin->group, M, g.lin->N, g.K, g.y, g.ldy, false,
-                                     R.gemm_ws, R.gemm_ws_bytes, g.swiglu));
-        prof_end(R, &ev);
-        return 0;
-    };
-    auto plain_attn = [&](int l, int64_t b0, int64_t nb) -> int {
-        const KvAddr kv = make_kv_addr(d, Hkv, D, R.kv_tokens, R.kv_cache, R.kv_scale, l);
-        prof_begin(c, R, PPLHIP_PROF_ATTN_DECODE, &ev);
-        HIPCK(c, rank, launch_attn_decode(s, R.qkv, kv, d.cache_quant_bit, R.d_seq + b0, R.d_sp + b0, R.d_ci + b0 * ci_stride, R.max_pages,
-                                          nb, H, Hkv, D, R.max_kv_len, 1, 256, R.attn_ws, R.att + b0 * (int64_t)H * D));
-        prof_end(R, &ev);
-        return 0;
-    };
-    // attention of requests [b0, b0 + nb) at layer la  ||  GEMM g over the M rows of the other half
-    auto fused = [&](int la, int64_t b0, int64_t nb, const Gemm& g, int64_t M) -> int {
-        if (nb <= 0) return plain_gemm(g, M);
-        const KvAddr kv = make_kv_addr(d, Hkv, D, R.kv_tokens, R.kv_cache, R.kv_scale, la);
-        prof_begin(c, R, PPLHIP_PROF_FUSED, &ev);
-        HIPCK(c, rank, launch_fused_attn_gemm(s, R.qkv, kv, d.cache_quant_bit, R.d_seq + b0, R.d_sp + b0, R.d_ci + b0 * ci_stride,
-                                              R.max_pages, nb, H, Hkv, R.att + b0 * (int64_t)H * D, g.x, g.lin->w, g.lin->scale, M,
-                                              g.lin->N, g.K, g.y, g.ldy, g.swiglu));
-        prof_end(R, &ev);
-        return 0;
-    };
-    auto norm_attn = [&](int l, const Chunk& k, bool first) -> int {  // (Skip)RMSNorm in front of wqkv
-        uint16_t* h = R.h + k.t0 * hd;
-        HIPCK(c, rank, launch_rmsnorm(s, h, first ? nullptr : R.part2 + k.t0 * hd, R.layers[l].attn_norm, d.norm_eps, k.tn, hd, nullptr,
-                                      R.xn + k.t0 * hd, first ? nullptr : h));
-        return 0;
-    };
-    auto norm_ffn = [&](int l, const Chunk& k) -> int {               // SkipRMSNorm in front of w13
-        uint16_t* h = R.h + k.t0 * hd;
-        HIPCK(c, rank, launch_rmsnorm(s, h, R.part + k.t0 * hd, R.layers[l].ffn_norm, d.norm_eps, k.tn, hd, nullptr, R.xn + k.t0 * hd, h));
-        return 0;
-    };
-    auto rope = [&](int l, const Chunk& k) -> int {
-        const KvAddr kv = make_kv_addr(d, Hkv, D, R.kv_tokens, R.kv_cache, R.kv_scale, l);
-        HIPCK(c, rank, launch_rope_kv_write(s, R.qkv, R.rope, kv, d.cache_quant_bit, d.cache_quant_group, R.d_seq, R.d_sp, R.d_ci,
-                                            R.max_pages, R.B, k.t0, k.tn, H, Hkv, D));
-        return 0;
-    };
-    // one slot: half `ya` attends at layer la while half `xc` runs its chain of layer lx (and wqkv of lx + 1)
-    auto slot = [&](const Chunk& ya, int la, const Chunk& xc, int lx) -> int {
-        const bool next = lx + 1 < nl;
-        Gemm g[4] = {gemm_of(WO, lx, xc), gemm_of(W13, lx, xc), gemm_of(W2, lx, xc), gemm_of(WQKV, next ? lx + 1 : lx, xc)};
-        const int ng = next ? 4 : 3;
-        double work[4], total = 0;
-        for (int i = 0; i < ng; ++i) { work[i] = (double)g[i].lin->N * g[i].K; total += work[i]; }
-        int64_t cut[5] = {0, 0, 0, 0, 0};
-        double cum = 0;
-        for (int i = 0; i < ng; ++i) { cum += work[i]; cut[i + 1] = i + 1 == ng ? ya.bn : (int64_t)(ya.bn * (cum / total) + 0.5); }
-        int rc;
-        if ((rc = fused(la, ya.b0 + cut[0], cut[1] - cut[0], g[0], xc.tn))) return rc;
-        if ((rc = norm_ffn(lx, xc))) return rc;
-        if ((rc = fused(la, ya.b0 + cut[1], cut[2] - cut[1], g[1], xc.tn))) return rc;
-        if ((rc = fused(la, ya.b0 + cut[2], cut[3] - cut[2], g[2], xc.tn))) return rc;
-        if (next) {
-            if ((rc = norm_attn(lx + 1, xc, false))) return rc;
-            if ((rc = fused(la, ya.b0 + cut[3], cut[4] - cut[3], g[3], xc.tn))) return rc;
-            if ((rc = rope(lx + 1, xc))) return rc;
-        }
-        return 0;
-    };
-
-    int rc;
-    const Chunk all{0, B, 0, B, B};
-    if ((rc = norm_attn(0, all, true))) return rc;
-    if ((rc = plain_gemm(gemm_of(WQKV, 0, all), B))) return rc;
-    if ((rc = rope(0, all))) return rc;
-    if ((rc = plain_attn(0, hv[0].b0, hv[0].bn))) return rc;
-    for (int l = 0; l < nl; ++l) {
-        if ((rc = slot(hv[1], l, hv[0], l))) return rc;
-        if (l + 1 < nl && (rc = slot(hv[0], l + 1, hv[1], l))) return rc;
-    }
-    // the second half's chain of the last layer has no attention left to run beside
-    if ((rc = plain_gemm(gemm_of(WO, nl - 1, hv[1]), hv[1].tn))) return rc;
-    if ((rc = norm_ffn(nl - 1, hv[1]))) return rc;
-    if ((rc = plain_gemm(gemm_of(W13, nl - 1, hv[1]), hv[1].tn))) return rc;
-    if ((rc = plain_gemm(gemm_of(W2, nl - 1, hv[1]), hv[1].tn))) return rc;
-    return 0;
-}
-
 int pplhip_run(pplhip_ctx* c, int rank, int cache_prefill) {
     (void)cache_prefill;  // K6 and K7 are one kernel here: attention always reads K/V back from the slab
     if (!c || rank < 0 || rank >= (int)c->ranks.size()) return PPLHIP_INVALID_VALUE;
@@ -1029,12 +895,7 @@ int pplhip_run(pplhip_ctx* c, int rank, int cache_prefill) {
     HIPCK(c, rank, launch_embedding(s, R.d_tok, R.embed, T, hd, R.h));
     const uint16_t* pending = nullptr;
     int rc;
-    const bool fused = fused_decode_applies(c, R, nb_decode, threads);
-    if (fused) {
-        if ((rc = run_decode_fused(c, rank))) return rc;
-        pending = R.part2;
-    }
-    for (int l = 0; l < (fused ? 0 : d.num_layers); ++l) {
+    for (int l = 0; l < d.num_layers; ++l) {
         for (int i = 0; i < nck; ++i) {
             if (ov && l > 0) HIPCK(c, rank, hipStreamWaitEvent(s, R.ev_comm[i], 0));  // part2 rows of chunk i are reduced
             if ((rc = layer_attention_part(c, rank, l, ck[i], pending, split[i], threads))) return rc;
@@ -1272,17 +1133,6 @@ int pplhip_op_attention(void* stream, const void* qkv, const pplhip_kv_view* kv,
         e = launch_attn_prefill(s, (const uint16_t*)qkv, a, kv->quant_bit, seq_starts, start_pos, cache_indices, max_pages, nb, B,
                                 num_heads, kv->kv_heads, kv->head_dim, max_seq_len, (uint16_t*)out);
     return op_rc(e);
-}
-
-int pplhip_op_attention_linear(void* stream, const void* qkv, const pplhip_kv_view* kv, const int64_t* seq_starts,
-                               const int64_t* start_pos, const int64_t* cache_indices, int64_t max_pages, int64_t B, int32_t num_heads,
-                               void* attn_out, const void* x, const void* w, const void* scale, int64_t M, int32_t N, int32_t K, void* y,
-                               int32_t swiglu) {
-    if (!kv || !qkv || !x || !w || !scale || !y || !attn_out || B <= 0 || M <= 0) return PPLHIP_INVALID_VALUE;
-    if (!fused_attn_gemm_supported(kv->quant_bit, kv->head_dim, num_heads, kv->kv_heads, 8, K, N)) return PPLHIP_INVALID_VALUE;
-    return op_rc(launch_fused_attn_gemm((hipStream_t)stream, (const uint16_t*)qkv, view_addr(kv), kv->quant_bit, seq_starts, start_pos,
-                                        cache_indices, max_pages, B, num_heads, kv->kv_heads, (uint16_t*)attn_out, (const uint16_t*)x,
-                                        w, (const uint16_t*)scale, M, N, K, y, swiglu ? N / 2 : N, swiglu != 0));
 }
 
 }  // extern "C"

@@ -19,7 +19,7 @@ _LIB = None
 STATUS = {0: "SUCCESS", -1: "OTHER_ERROR", -2: "INVALID_VALUE", -3: "OUT_OF_MEMORY", -4: "DEVICE_RUNTIME_ERROR",
           -5: "DEVICE_MEMORY_ERROR", -6: "NOT_FOUND", -7: "UNSUPPORTED"}
 
-PROF_ATTN_DECODE, PROF_ATTN_PREFILL, PROF_GEMM, PROF_RUN, PROF_FUSED = 0, 1, 2, 3, 4
+PROF_ATTN_DECODE, PROF_ATTN_PREFILL, PROF_GEMM, PROF_RUN = 0, 1, 2, 3
 
 
 class PplHipError(RuntimeError):
@@ -75,7 +75,7 @@ SYMBOLS = [
     "pplhip_kv_write", "pplhip_kv_fill_synthetic", "pplhip_set_inputs", "pplhip_run", "pplhip_logits", "pplhip_copy_logits", "pplhip_sync",
     "pplhip_sample", "pplhip_penalty", "pplhip_profile_reset", "pplhip_profile_get", "pplhip_mem_info",
     "pplhip_op_embedding", "pplhip_op_rmsnorm", "pplhip_op_linear", "pplhip_op_linear_swiglu", "pplhip_op_silu_mul", "pplhip_op_rope_kv_write",
-    "pplhip_op_attention", "pplhip_op_attention_linear", "pplhip_build_rope_table",
+    "pplhip_op_attention", "pplhip_build_rope_table",
 ]
 
 
@@ -124,8 +124,6 @@ def lib():
         L.pplhip_op_rope_kv_write.argtypes = [vp, vp, vp, C.POINTER(KvView), vp, vp, vp, i64, i64, i64, i32]
         L.pplhip_op_attention.argtypes = [vp, vp, C.POINTER(KvView), vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, i32,
                                           vp, u64, vp]
-        L.pplhip_op_attention_linear.argtypes = [vp, vp, C.POINTER(KvView), vp, vp, vp, i64, i64, i32, vp, vp, vp, vp, i64, i32, i32,
-                                                 vp, i32]
         L.pplhip_build_rope_table.argtypes = [vp, i32, i32, f32]
         _LIB = L
     return _LIB

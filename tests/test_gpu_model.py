@@ -194,75 +194,6 @@ def test_comm_path_and_chunked_overlap_single_gpu(monkeypatch, init):
         assert np.abs(a[0] - b[0]).max() <= 4e-3 * max(1.0, np.abs(a[0]).max())
 
 
-@pytest.mark.parametrize("kvq,mode,nreq", [(8, 1, 37), (0, 0, 9), (8, 0, 300)])
-def test_role_fused_decode_schedule(monkeypatch, kvq, mode, nreq):
-    """pure-decode steps through the role-fused schedule (two half batches half a layer apart, every GEMM of one half launched
-    together with a slice of the other half's attention, k_fused.hip) against the oracle and against the plain schedule
-    (tolerance: the plain schedule may split K at these tiny shapes)."""
-    m = load_pplhip()
-    desc = ref.make_desc(hidden_dim=256, intermediate_dim=512, num_layers=3, num_heads=2, num_kv_heads=2, vocab_size=1024,
-                         max_position=256, cache_quant_bit=kvq, cache_quant_group=8 if kvq else 1, cache_layout=3,
-                         cache_mode=mode, page_size=16 if mode else 0, weight_quant_bit=8)
-    rng = np.random.RandomState(5)
-    prompts = [rng.randint(3, 1024, size=int(n)) for n in rng.randint(1, 40, size=nreq)]
-    rm = ref.RefModel(desc)
-    rm.init_synthetic(42)
-    kv_tokens = 16384
-    rm.kv_alloc(kv_tokens)
-
-    def run(fused):
-        monkeypatch.setenv("PPLHIP_FUSED_DECODE", "1" if fused else "0")
-        monkeypatch.setenv("PPLHIP_FUSED_MIN_BATCH", "2")
-        ctx = m.Context(m.copy_desc(desc), max_running_batch=512, max_tokens_per_step=8192, profiling=True)
-        ctx.init_synthetic(0, 42)
-        ctx.kv_alloc(0, kv_tokens)
-        rm.kv_array(0)[:] = 0
-        ctx.profile_reset(0)
-        res = generate_both(m, ctx, [rm], desc, prompts, 3, kv_tokens)
-        n_fused, _ = ctx.profile_get(m.PROF_FUSED)
-        ctx.close()
-        return res, n_fused
-
-    plain, n0 = run(False)
-    fused, n1 = run(True)
-    full = 2 * (8 * desc.num_layers - 5)   # two decode steps; 2L - 1 slots of 4 launches, the last one of 3
-    assert n0 == 0 and 0 < n1 <= full and (n1 == full or nreq < 37)   # (an empty attention slice falls back to the plain GEMM)
-    check_steps(fused, k=8)
-    for a, b in zip(plain, fused):
-        assert np.abs(a[0] - b[0]).max() <= 4e-3 * max(1.0, np.abs(a[0]).max())
-
-
-def test_role_fused_decode_matches_plain_schedule_at_the_benchmark_shape(monkeypatch):
-    """LLaMA-7B layer shapes (2 layers), 1024 requests: neither schedule splits K where they overlap and the role-fused launches
-    run the same kernel bodies on the same rows, so the first half batch must be identical bit for bit; the second half's last
-    three GEMMs run as plain launches over 512 rows, which the launcher splits along K (rounding-level difference)."""
-    m = load_pplhip()
-    desc = ref.make_desc(hidden_dim=4096, intermediate_dim=11008, num_layers=2, num_heads=32, num_kv_heads=32, vocab_size=32000,
-                         max_position=256, cache_quant_bit=8, cache_quant_group=8, cache_layout=3, cache_mode=0,
-                         weight_quant_bit=8)
-    B, ctx_len = 1024, 40
-    rng = np.random.RandomState(1)
-    tok = rng.randint(3, 32000, size=B).astype(np.int64)
-    start_pos = rng.randint(1, ctx_len, size=B).astype(np.int64)
-    cache_idx = (np.arange(B) * (ctx_len + 1)).astype(np.int64)
-    out = []
-    for fused in (0, 1):
-        monkeypatch.setenv("PPLHIP_FUSED_DECODE", str(fused))
-        ctx = m.Context(m.copy_desc(desc), max_running_batch=B, max_tokens_per_step=B, profiling=True)
-        ctx.init_synthetic(0, 9)
-        ctx.kv_alloc(0, B * (ctx_len + 1))
-        ctx.kv_fill_synthetic(0, 3)
-        ctx.profile_reset(0)
-        ctx.set_inputs(0, m.make_step(tok, np.arange(B + 1), start_pos, cache_idx, B, 0, req_list_changed=1))
-        ctx.run(0)
-        out.append(ctx.copy_logits(B).copy())
-        assert (ctx.profile_get(m.PROF_FUSED)[0] > 0) == bool(fused)
-        ctx.close()
-    assert np.isfinite(out[0]).all() and np.abs(out[0]).max() > 0
-    assert (out[0][:512] == out[1][:512]).all()
-    assert np.abs(out[0] - out[1]).max() <= 1e-3 * max(1.0, np.abs(out[0]).max())
-
-
 def test_container_load_and_errors(golden_dir):
     m = load_pplhip()
     meta, weights, prompts, hf_logits, _, _ = load_fixture(os.path.join(golden_dir, "hf_tiny_mha.npz"))

@@ -395,56 +395,3 @@ def test_linear_swiglu_fused(wq, M, inter, K):
     mag = np.abs(want).max()
     rel = 6e-3 if wq == 4 else 3e-3   # two fp16 roundings upstream of the product
     close_f16(y.cpu().numpy(), want, rel=rel, abs_=rel * mag * (0.25 if wq == 4 else 0.05) + 1e-5)
-
-
-@pytest.mark.parametrize("quant,mode", [(8, 0), (0, 1), (8, 1)])
-@pytest.mark.parametrize("M,N,K,swiglu", [(130, 320, 128, 0), (257, 1024, 4096, 0), (300, 2752, 512, 1), (64, 4096, 1408, 0)])
-def test_attention_linear_one_launch(quant, mode, M, N, K, swiglu):
-    """the role-fused launch (pplhip_op_attention_linear): decode attention of one set of requests and a W8A16 GEMM of
-    unrelated rows in ONE kernel -- each half against its oracle."""
-    m = load_pplhip()
-    H = Hkv = 3
-    D = 128
-    kvlen = [1, 2, 63, 64, 65, 257, 700, 33, 16, 129]
-    case = KvCase(m, H, Hkv, D, L=2, layer=1, quant=quant, layout=3, mode=mode, seqlens=[1] * len(kvlen),
-                  start_pos=[k - 1 for k in kvlen], seed=quant + mode, page_size=16, decoding_batches=len(kvlen))
-    rng = np.random.RandomState(M + N)
-    if quant:
-        case.cache[:] = rng.randint(-127, 128, size=case.cache.size).astype(np.int8)
-        case.scale[:] = f16(0.02 * (0.5 + rng.rand(case.scale.size)))
-    else:
-        case.cache[:] = f16(rng.randn(case.cache.size))
-    q32 = case.ref_write()
-    want_att = case.ref_attention(q32)
-    x = f16(rng.randn(M, K) * 0.5)
-    w = rng.randint(-127, 128, size=(N, K)).astype(np.int8)
-    scale = f16(0.0008 * (0.5 + rng.rand(N)))
-    want = np.empty((M, N), dtype=np.float32)
-    xs = x.astype(np.float32)
-    ref.lib().ref_linear_raw(xs.ctypes.data, w.ctypes.data, scale.ctypes.data, 8, 128, M, N, K, want.ctypes.data, 0)
-    ncol = N
-    if swiglu:
-        inter = N // 2
-        gu, want = want, np.empty((M, inter), dtype=np.float32)
-        ref.lib().ref_silu_mul(gu.ctypes.data, M, inter, want.ctypes.data)
-        perm = np.empty(N, dtype=np.int64)
-        perm[0::2], perm[1::2] = np.arange(inter), inter + np.arange(inter)
-        w, scale, ncol = np.ascontiguousarray(w[perm]), np.ascontiguousarray(scale[perm]), inter
-    dq = dev(q32.astype(np.float16))
-    dcache, dscale = dev(case.cache), (dev(case.scale) if quant else None)
-    v = case.view(dcache, dscale)
-    args = (dev(case.seq_starts), dev(case.start_pos), dev(case.cache_idx))
-    out = torch.zeros((case.T, H * D), dtype=torch.float16, device="cuda")
-    y = torch.empty((M, ncol), dtype=torch.float16, device="cuda")
-    dx, dw, ds = dev(x), dev(w), dev(scale)
-    ck(m.lib().pplhip_op_attention_linear(None, dq.data_ptr(), C.byref(v), args[0].data_ptr(), args[1].data_ptr(), args[2].data_ptr(),
-                                          case.max_pages, case.B, H, out.data_ptr(), dx.data_ptr(), dw.data_ptr(), ds.data_ptr(), M, N, K,
-                                          y.data_ptr(), swiglu))
-    close_f16(out.cpu().numpy(), want_att, rel=1.5e-3, abs_=1.5e-3)
-    mag = np.abs(want).max()
-    rel = 3e-3 if swiglu else 1.5e-3
-    close_f16(y.cpu().numpy(), want, rel=rel, abs_=rel * mag * 0.05 + 1e-5)
-    # unsupported shapes are refused, not mis-computed
-    assert m.lib().pplhip_op_attention_linear(None, dq.data_ptr(), C.byref(v), args[0].data_ptr(), args[1].data_ptr(), args[2].data_ptr(),
-                                              case.max_pages, case.B, H, out.data_ptr(), dx.data_ptr(), dw.data_ptr(), ds.data_ptr(), M, N,
-                                              K + 32, y.data_ptr(), swiglu) != 0
