@@ -150,6 +150,20 @@ PPLHIP_API int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opt
 
 PPLHIP_API void pplhip_destroy(pplhip_ctx* ctx);
 
+/* ---- tensor-parallel collectives (replaces the NCCL calls ppl.nn issues on the engine's stream,
+ *      src/backends/cuda/resource_manager.cc:239,392-398) ------------------------------------------------
+ * Two implementations behind the same step schedule: RCCL, and direct kernels over peer-mapped memory that use all
+ * xGMI links of a rank at once (csrc/k_comm.hip).  The direct path is preferred whenever its start-up self-test passes
+ * on EVERY rank (env PPLHIP_COMM=auto|p2p|rccl).  When all ranks live in one process (the reference's mode)
+ * pplhip_init connects them itself.  With one process per GPU the launcher does, after pplhip_init on every process:
+ *     pplhip_comm_export(ctx, 0, mine);  all-gather the handles by global rank;  pplhip_comm_connect(ctx, all);
+ * pplhip_comm_connect is collective (every process calls it at about the same time); skipping it keeps RCCL. */
+#define PPLHIP_IPC_HANDLE_BYTES 64
+PPLHIP_API int pplhip_comm_export(pplhip_ctx* ctx, int rank, void* handle_out /* PPLHIP_IPC_HANDLE_BYTES */);
+PPLHIP_API int pplhip_comm_connect(pplhip_ctx* ctx, const void* all_handles /* world_size x PPLHIP_IPC_HANDLE_BYTES */);
+/* collectives in use: 0 none (single rank), 1 RCCL, 2 direct kernels over peer-mapped memory */
+PPLHIP_API int pplhip_comm_mode(pplhip_ctx* ctx);
+
 PPLHIP_API const char* pplhip_last_error(pplhip_ctx* ctx, int rank);
 
 /* ================================================================================================

@@ -56,6 +56,24 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
 // dst row r = src row perm(r): r even -> r/2 (gate), r odd -> half + r/2 (up).  row_bytes % 4 == 0.
 hipError_t launch_interleave_rows(hipStream_t s, const void* src, void* dst, int rows, int64_t row_bytes);
 
+// ---- k_comm.hip ------------------------------------------------------------------------------
+// direct (all-links) tensor-parallel collectives over peer-mapped exchange regions; see the file header.
+constexpr int P2P_MAX_RANKS = 8;
+constexpr int P2P_MAX_BLOCKS = 64;
+// exchange-region layout (bytes, identical on every rank): flag words first, data buffers after P2P_DATA_START
+constexpr size_t P2P_FLAGS_START = 0;                                         // uint32 [P2P_MAX_BLOCKS][P2P_MAX_RANKS]
+constexpr size_t P2P_FLAGS_END = (size_t)P2P_MAX_BLOCKS * P2P_MAX_RANKS * 4;  // uint32 [P2P_MAX_BLOCKS][P2P_MAX_RANKS]
+constexpr size_t P2P_DATA_START = 8192;
+struct P2pPeers {
+    char* base[P2P_MAX_RANKS];  // exchange region of every rank as mapped in this process (base[me] is the local one)
+};
+// in-place all-reduce(sum) of fp16[count] at byte offset data_off of every rank's region (count % 4 == 0)
+hipError_t launch_p2p_allreduce(hipStream_t s, const P2pPeers& peers, int me, int n, size_t data_off, int64_t count, uint32_t epoch,
+                                uint64_t timeout_ticks, uint32_t* status);
+// src[bytes] (ordinary local memory) -> bytes at dst_off + me * slot_bytes of every rank's region
+hipError_t launch_p2p_allgather(hipStream_t s, const P2pPeers& peers, int me, int n, const void* src, size_t dst_off, int64_t bytes,
+                                int64_t slot_bytes, uint32_t epoch, uint64_t timeout_ticks, uint32_t* status);
+
 // ---- k_sample.hip -----------------------------------------------------------------------------
 hipError_t launch_sample_greedy(hipStream_t s, const float* logits, const float* temperatures, int batch, int vocab,
                                 int stride, int32_t* out_tok, float* out_logprob);

@@ -101,6 +101,16 @@ struct Rank {
     float *d_rep = nullptr, *d_pres = nullptr, *d_freq = nullptr, *d_ptemp = nullptr;
     float* h_rand = nullptr;  // pinned
 
+    // exchange region of the direct collectives (k_comm.hip): uncached, peer-mapped; holds the flag words and the buffers
+    // the collectives work in place on (part, part2) or push into (logits_gather)
+    char* xbase = nullptr;
+    size_t xbytes = 0, x_part = 0, x_part2 = 0, x_gather = 0;  // byte offsets inside the region
+    P2pPeers peers{};
+    bool peer_ipc[P2P_MAX_RANKS] = {};  // peers.base[g] came from hipIpcOpenMemHandle (closed on destroy)
+    uint32_t p2p_epoch = 0;
+    uint32_t* p2p_status = nullptr;     // pinned host word a kernel raises when one of its bounded spins timed out
+    int32_t* d_flag = nullptr;          // one int for the cross-process agreement on the self-test
+
     // profiling
     std::vector<ProfEvent> prof;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_free;
@@ -119,6 +129,13 @@ struct pplhip_ctx {
     // of 8 MB it hides are worth -- so it is used for steps that carry prefill tokens (T >= 2048: 16+ MB per
     // all-reduce, chunks of >= 1024 rows keep the GEMM tiles full), not for pure decode steps of <= 1024 rows.
     int64_t tp_overlap_min_tokens = 2048;
+    bool tp_on = false;     // the tensor-parallel step schedule (collectives after wo / w2, logits gather) is active
+    // collectives: 2 = direct kernels over peer-mapped memory (k_comm.hip), 1 = RCCL, 0 = none.  PPLHIP_COMM=auto (default:
+    // direct when the self-test passes on every rank, else RCCL) | p2p (direct or fail) | rccl
+    int comm_mode = 0;
+    int comm_want = 0;      // 0 auto, 1 rccl only, 2 p2p only
+    bool p2p_connected = false;
+    uint64_t p2p_timeout_ticks = 0;  // s_memrealtime ticks (100 MHz)
     int H = 0, Hkv = 0, D = 0, inter = 0, vocab_local = 0;
     std::vector<Rank> ranks;
     std::string err;
@@ -240,6 +257,120 @@ int decode_split(const pplhip_ctx* c, int64_t nb, int64_t max_kv_len) {
     return split;
 }
 
+// ---- direct collectives: connection + self-test -------------------------------------------------------------------------
+
+// the direct path cannot be used: an error when it was demanded (or no RCCL communicator exists), else RCCL stays in charge
+int p2p_unavailable(pplhip_ctx* c, int rank, const std::string& why) {
+    if (c->comm_want == 2 || c->comm_mode != 1) return fail(c, rank, PPLHIP_DEVICE_RUNTIME_ERROR, "direct collectives unavailable: " + why);
+    if (getenv("PPLHIP_VERBOSE")) fprintf(stderr, "[pplhip] direct collectives unavailable (%s): using RCCL\n", why.c_str());
+    return 0;
+}
+
+// Runs both collectives twice on known patterns on every local rank (all ranks of the group do this at the same time,
+// in this process or in others) and compares with the exact answer.  Every rank then learns whether ALL ranks passed
+// (one RCCL all-reduce when a communicator exists); only then comm_mode becomes 2.
+int p2p_selftest(pplhip_ctx* c) {
+    const int n = (int)c->ranks.size(), tp = c->tp, hd = c->d.hidden_dim;
+    const int64_t cnt = std::min<int64_t>((int64_t)1 << 20, c->ranks[0].cap_T * (int64_t)hd) / 4 * 4;
+    const int64_t gcnt = std::min<int64_t>((int64_t)1 << 18, c->ranks[0].cap_B * (int64_t)c->vocab_local) / 2 * 2;  // floats
+    const char* e = getenv("PPLHIP_P2P_SELFTEST_MS");
+    const uint64_t ticks = (uint64_t)(e ? std::max(1, atoi(e)) : 10000) * 100000ull;
+    auto pat = [](int64_t i, int g, int round) { return (float)((int)((i * 7 + g * 13 + round * 5) % 64) - 32) * 0.25f; };
+    bool ok = true;
+    std::string why;
+    std::vector<uint16_t> hbuf(cnt);
+    std::vector<float> gbuf(gcnt), gall;
+    for (int round = 0; round < 2 && ok; ++round) {
+        for (int r = 0; r < n; ++r) {
+            Rank& R = c->ranks[r];
+            HIPCK(c, r, hipSetDevice(R.device));
+            for (int64_t i = 0; i < cnt; ++i) hbuf[i] = __builtin_bit_cast(uint16_t, (_Float16)pat(i, R.global_rank, round));
+            for (int64_t i = 0; i < gcnt; ++i) gbuf[i] = pat(i, R.global_rank, round + 2);
+            HIPCK(c, r, hipMemcpy(R.part, hbuf.data(), cnt * 2, hipMemcpyHostToDevice));
+            HIPCK(c, r, hipMemcpy(R.logits_local, gbuf.data(), gcnt * 4, hipMemcpyHostToDevice));
+        }
+        for (int r = 0; r < n; ++r) {
+            Rank& R = c->ranks[r];
+            HIPCK(c, r, hipSetDevice(R.device));
+            HIPCK(c, r, launch_p2p_allreduce(R.stream, R.peers, R.global_rank, tp, R.x_part, cnt, ++R.p2p_epoch, ticks, R.p2p_status));
+            HIPCK(c, r, launch_p2p_allgather(R.stream, R.peers, R.global_rank, tp, R.logits_local, R.x_gather, gcnt * 4, gcnt * 4,
+                                             ++R.p2p_epoch, ticks, R.p2p_status));
+        }
+        for (int r = 0; r < n && ok; ++r) {
+            Rank& R = c->ranks[r];
+            HIPCK(c, r, hipSetDevice(R.device));
+            HIPCK(c, r, hipStreamSynchronize(R.stream));
+            if (*R.p2p_status) { ok = false; why = "spin timed out (status " + std::to_string(*R.p2p_status) + ")"; *R.p2p_status = 0; break; }
+            HIPCK(c, r, hipMemcpy(hbuf.data(), R.part, cnt * 2, hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < cnt && ok; ++i) {
+                float want = 0.f;
+                for (int g = 0; g < tp; ++g) want += pat(i, g, round);
+                if ((float)__builtin_bit_cast(_Float16, hbuf[i]) != want) { ok = false; why = "all-reduce mismatch at element " + std::to_string(i); }
+            }
+            gall.resize((size_t)gcnt * tp);
+            HIPCK(c, r, hipMemcpy(gall.data(), R.logits_gather, gall.size() * 4, hipMemcpyDeviceToHost));
+            for (int g = 0; g < tp && ok; ++g)
+                for (int64_t i = 0; i < gcnt && ok; ++i)
+                    if (gall[(size_t)g * gcnt + i] != pat(i, g, round + 2)) { ok = false; why = "all-gather mismatch in slot " + std::to_string(g); }
+        }
+    }
+    // agreement: min over all ranks of the group
+    if (c->comm_mode == 1) {
+        for (int r = 0; r < n; ++r) {
+            Rank& R = c->ranks[r];
+            HIPCK(c, r, hipSetDevice(R.device));
+            const int32_t v = ok ? 1 : 0;
+            HIPCK(c, r, hipMemcpy(R.d_flag, &v, 4, hipMemcpyHostToDevice));
+        }
+        NCCLCK(c, -1, ncclGroupStart());
+        for (int r = 0; r < n; ++r) NCCLCK(c, r, ncclAllReduce(c->ranks[r].d_flag, c->ranks[r].d_flag, 1, ncclInt32, ncclMin, c->ranks[r].comm, c->ranks[r].stream));
+        NCCLCK(c, -1, ncclGroupEnd());
+        for (int r = 0; r < n; ++r) {
+            Rank& R = c->ranks[r];
+            HIPCK(c, r, hipSetDevice(R.device));
+            HIPCK(c, r, hipStreamSynchronize(R.stream));
+            int32_t v = 0;
+            HIPCK(c, r, hipMemcpy(&v, R.d_flag, 4, hipMemcpyDeviceToHost));
+            if (!v && ok) { ok = false; why = "another rank failed its self-test"; }
+        }
+    }
+    if (!ok) return p2p_unavailable(c, 0, "self-test: " + why);
+    c->comm_mode = 2;
+    if (getenv("PPLHIP_VERBOSE")) fprintf(stderr, "[pplhip] direct collectives over peer-mapped memory: self-test passed on %d local rank(s) of %d\n", n, tp);
+    return 0;
+}
+
+// all ranks of the group are in this process (the reference's mode, resource_manager.cc:392-422)
+int p2p_connect_local(pplhip_ctx* c) {
+    const int n = (int)c->ranks.size();
+    for (int r = 0; r < n; ++r) {
+        Rank& R = c->ranks[r];
+        HIPCK(c, r, hipSetDevice(R.device));
+        for (int g = 0; g < n; ++g) {
+            Rank& Q = c->ranks[g];
+            if (Q.device != R.device) {
+                hipError_t e = hipDeviceEnablePeerAccess(Q.device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); return p2p_unavailable(c, r, std::string("peer access: ") + hipGetErrorString(e)); }
+                (void)hipGetLastError();
+            }
+            R.peers.base[g] = Q.xbase;
+        }
+    }
+    c->p2p_connected = true;
+    return p2p_selftest(c);
+}
+
+// a kernel of the direct path gave up waiting for a peer: surfaced at the step's synchronisation points
+int p2p_check(pplhip_ctx* c, int rank) {
+    Rank& R = c->ranks[rank];
+    if (R.p2p_status && *R.p2p_status) {
+        const uint32_t v = *R.p2p_status;
+        return fail(c, rank, PPLHIP_DEVICE_RUNTIME_ERROR, "direct collective timed out waiting for rank " + std::to_string((v - 1) & 15) +
+                    ((v - 1) & 16 ? " (end barrier)" : " (start barrier)"));
+    }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -288,6 +419,10 @@ void pplhip_destroy(pplhip_ctx* c) {
         for (auto& e : R.prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
         for (auto& p : R.prof_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
         for (void* p : R.allocs) hipFree(p);
+        for (int g = 0; g < P2P_MAX_RANKS; ++g)
+            if (R.peer_ipc[g] && R.peers.base[g]) hipIpcCloseMemHandle(R.peers.base[g]);
+        if (R.xbase) hipFree(R.xbase);
+        if (R.p2p_status) hipHostFree(R.p2p_status);
         if (R.kv_cache) hipFree(R.kv_cache);
         if (R.kv_scale) hipFree(R.kv_scale);
         for (int i = 0; i < 2; ++i) {
@@ -350,9 +485,26 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
     // PPLHIP_FORCE_COMM=1: create the communicator and run every collective even at world size 1 (an identity) --
     // lets a single-GPU box exercise the RCCL call sequence, the communication stream and its event wiring
     const bool want_comm = tp > 1 || getenv("PPLHIP_FORCE_COMM") != nullptr;
+    c->tp_on = want_comm;
+    if (const char* e = getenv("PPLHIP_COMM")) c->comm_want = !strcmp(e, "rccl") ? 1 : (!strcmp(e, "p2p") ? 2 : 0);
+    {   // bounded spins of the direct collectives: s_memrealtime runs at 100 MHz
+        const char* e = getenv("PPLHIP_P2P_TIMEOUT_MS");
+        c->p2p_timeout_ticks = (uint64_t)(e ? std::max(1, atoi(e)) : 20000) * 100000ull;
+    }
+    // several ranks on ONE device (tests: a whole tensor-parallel group emulated on a single GPU): RCCL refuses duplicate
+    // devices, the direct collectives do not care where a peer's region lives
+    bool dup_dev = false;
+    for (int a = 0; a < n; ++a)
+        for (int b = a + 1; b < n; ++b) dup_dev |= devs[a] == devs[b];
+    if (dup_dev && c->comm_want == 1) return fail(cp, -1, PPLHIP_INVALID_VALUE, "PPLHIP_COMM=rccl needs distinct devices");
+    if (dup_dev) c->comm_want = 2;
+    if (tp > P2P_MAX_RANKS || getenv("PPLHIP_EMULATE_TP") || tp < 2) {
+        if (c->comm_want == 2 && want_comm) return fail(cp, -1, PPLHIP_INVALID_VALUE, "direct collectives need 2..8 connected ranks");
+        c->comm_want = 1;
+    }
     if (const char* e = getenv("PPLHIP_TP_OVERLAP")) c->tp_overlap = atoi(e) != 0;
     if (const char* e = getenv("PPLHIP_TP_OVERLAP_MIN_TOKENS")) c->tp_overlap_min_tokens = std::max(2, atoi(e));
-    if (want_comm) {
+    if (want_comm && c->comm_want != 2) {
         std::vector<ncclComm_t> comms(n);
         // PPLHIP_EMULATE_TP=1 (measurement only): this process holds n of the tp slices but the communicator spans only
         // those n, so one GPU can time the per-rank work of a tp-way step (collectives become local identities and the
@@ -371,6 +523,7 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
             NCCLCK(cp, -1, ncclGroupEnd());
         }
         for (int r = 0; r < n; ++r) c->ranks[r].comm = comms[r];
+        c->comm_mode = 1;
     }
 
     const int64_t cap_B = opts->max_running_batch;
@@ -385,7 +538,7 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
         R.global_rank = opts->rank_base + r;
         HIPCK(cp, r, hipSetDevice(R.device));
         HIPCK(cp, r, hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
-        if (R.comm) {
+        if (c->tp_on) {
             HIPCK(cp, r, hipStreamCreateWithFlags(&R.comm_stream, hipStreamNonBlocking));
             for (int i = 0; i < 2; ++i) {
                 HIPCK(cp, r, hipEventCreateWithFlags(&R.ev_compute[i], hipEventDisableTiming));
@@ -424,17 +577,32 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
         ALLOC(R.xn, (uint64_t)cap_T * hd * 2);
         ALLOC(R.qkv, (uint64_t)cap_T * (c->H + 2 * c->Hkv) * c->D * 2);
         ALLOC(R.att, (uint64_t)cap_T * c->H * c->D * 2);
-        ALLOC(R.part, (uint64_t)cap_T * hd * 2);
-        ALLOC(R.part2, (uint64_t)cap_T * hd * 2);
+        if (!c->tp_on) {
+            ALLOC(R.part, (uint64_t)cap_T * hd * 2);
+            ALLOC(R.part2, (uint64_t)cap_T * hd * 2);
+        } else {
+            // the buffers collectives touch live in ONE uncached allocation that peers map (k_comm.hip); RCCL works on them too
+            auto up = [](size_t v) { return (v + 4095) / 4096 * 4096; };
+            R.x_part = P2P_DATA_START;
+            R.x_part2 = R.x_part + up((size_t)cap_T * hd * 2);
+            R.x_gather = R.x_part2 + up((size_t)cap_T * hd * 2);
+            R.xbytes = R.x_gather + up((size_t)cap_B * d.vocab_size * 4);
+            hipError_t e = hipExtMallocWithFlags((void**)&R.xbase, R.xbytes, hipDeviceMallocUncached);
+            if (e != hipSuccess) return fail(cp, r, PPLHIP_OUT_OF_MEMORY, std::string("exchange region: ") + hipGetErrorString(e));
+            HIPCK(cp, r, hipMemset(R.xbase, 0, P2P_DATA_START));
+            R.part = (uint16_t*)(R.xbase + R.x_part);
+            R.part2 = (uint16_t*)(R.xbase + R.x_part2);
+            R.logits_gather = (float*)(R.xbase + R.x_gather);
+            HIPCK(cp, r, hipHostMalloc((void**)&R.p2p_status, 64, hipHostMallocMapped));
+            *R.p2p_status = 0;
+            ALLOC(R.d_flag, 64);
+        }
         const int inter_p = (d.weight_quant_bit != 4) ? (c->inter + 63) / 64 * 64 : c->inter;  // = layers[*].w2.Kp
         ALLOC(R.act, (uint64_t)cap_T * inter_p * 2);
         if (inter_p != c->inter) HIPCK(cp, r, hipMemset(R.act, 0, (uint64_t)cap_T * inter_p * 2));  // pad columns stay zero
         ALLOC(R.hn, (uint64_t)cap_B * hd * 2);
         ALLOC(R.logits, (uint64_t)cap_B * d.vocab_size * 4);
-        if (R.comm) {
-            ALLOC(R.logits_local, (uint64_t)cap_B * c->vocab_local * 4);
-            ALLOC(R.logits_gather, (uint64_t)cap_B * d.vocab_size * 4);
-        }
+        if (c->tp_on) ALLOC(R.logits_local, (uint64_t)cap_B * c->vocab_local * 4);
         R.attn_ws_bytes = attn_decode_workspace_bytes(cap_B, c->H, c->D, 32);
         ALLOC(R.attn_ws, R.attn_ws_bytes);
         R.gemm_ws_bytes = (size_t)8 * 256 * (size_t)std::max(std::max(2 * c->inter, (c->H + 2 * c->Hkv) * c->D), std::max(hd, c->vocab_local)) * sizeof(float);
@@ -455,9 +623,62 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
 #undef ALLOC
         HIPCK(cp, r, hipDeviceSynchronize());
     }
+    // every rank of the group lives in this process: map the peers' regions now and try the direct collectives
+    if (c->tp_on && c->comm_want != 1 && tp == n) {
+        int rc = p2p_connect_local(cp);
+        if (rc) return rc;
+    }
     *out = c.release();
     return 0;
 }
+
+int pplhip_comm_export(pplhip_ctx* c, int rank, void* handle_out) {
+    if (!c || rank < 0 || rank >= (int)c->ranks.size() || !handle_out) return PPLHIP_INVALID_VALUE;
+    Rank& R = c->ranks[rank];
+    memset(handle_out, 0, PPLHIP_IPC_HANDLE_BYTES);
+    if (!R.xbase) return fail(c, rank, PPLHIP_INVALID_VALUE, "no exchange region (tensor parallelism is off)");
+    static_assert(sizeof(hipIpcMemHandle_t) <= PPLHIP_IPC_HANDLE_BYTES, "ipc handle size");
+    HIPCK(c, rank, hipSetDevice(R.device));
+    hipIpcMemHandle_t h;
+    HIPCK(c, rank, hipIpcGetMemHandle(&h, R.xbase));
+    memcpy(handle_out, &h, sizeof(h));
+    return 0;
+}
+
+int pplhip_comm_connect(pplhip_ctx* c, const void* all_handles) {
+    if (!c || !all_handles) return PPLHIP_INVALID_VALUE;
+    if (!c->tp_on || c->tp > P2P_MAX_RANKS) return fail(c, -1, PPLHIP_INVALID_VALUE, "nothing to connect");
+    if (c->comm_want == 1) return 0;  // PPLHIP_COMM=rccl
+    if (c->p2p_connected) return fail(c, -1, PPLHIP_INVALID_VALUE, "already connected");
+    const int n = (int)c->ranks.size(), base = c->o.rank_base;
+    for (int r = 0; r < n; ++r) {
+        Rank& R = c->ranks[r];
+        HIPCK(c, r, hipSetDevice(R.device));
+        for (int g = 0; g < c->tp; ++g) {
+            if (g >= base && g < base + n) {  // a rank of this process
+                Rank& Q = c->ranks[g - base];
+                if (Q.device != R.device) {
+                    hipError_t e = hipDeviceEnablePeerAccess(Q.device, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); return p2p_unavailable(c, r, std::string("peer access: ") + hipGetErrorString(e)); }
+                    (void)hipGetLastError();
+                }
+                R.peers.base[g] = Q.xbase;
+                continue;
+            }
+            hipIpcMemHandle_t h;
+            memcpy(&h, (const char*)all_handles + (size_t)g * PPLHIP_IPC_HANDLE_BYTES, sizeof(h));
+            void* ptr = nullptr;
+            hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) { (void)hipGetLastError(); return p2p_unavailable(c, r, std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e)); }
+            R.peers.base[g] = (char*)ptr;
+            R.peer_ipc[g] = true;
+        }
+    }
+    c->p2p_connected = true;
+    return p2p_selftest(c);
+}
+
+int pplhip_comm_mode(pplhip_ctx* c) { return c ? c->comm_mode : PPLHIP_INVALID_VALUE; }
 
 /* ------------------------------------------------------------------------------------------------ weights */
 
@@ -842,13 +1063,19 @@ static int chunk_allreduce(pplhip_ctx* c, int rank, uint16_t* buf, const Chunk& 
     Rank& R = c->ranks[rank];
     const int hd = c->d.hidden_dim;
     uint16_t* p = buf + k.t0 * hd;
-    if (!overlapped) {
-        NCCLCK(c, rank, ncclAllReduce(p, p, (size_t)k.tn * hd, ncclFloat16, ncclSum, R.comm, R.stream));
+    auto reduce_on = [&](hipStream_t st) -> int {
+        if (c->comm_mode == 2) {
+            HIPCK(c, rank, launch_p2p_allreduce(st, R.peers, R.global_rank, c->tp, (size_t)((char*)p - R.xbase), k.tn * hd, ++R.p2p_epoch,
+                                                c->p2p_timeout_ticks, R.p2p_status));
+        } else if (R.comm) {
+            NCCLCK(c, rank, ncclAllReduce(p, p, (size_t)k.tn * hd, ncclFloat16, ncclSum, R.comm, st));
+        }
         return 0;
-    }
+    };
+    if (!overlapped) return reduce_on(R.stream);
     HIPCK(c, rank, hipEventRecord(R.ev_compute[ci], R.stream));
     HIPCK(c, rank, hipStreamWaitEvent(R.comm_stream, R.ev_compute[ci], 0));
-    NCCLCK(c, rank, ncclAllReduce(p, p, (size_t)k.tn * hd, ncclFloat16, ncclSum, R.comm, R.comm_stream));
+    if (int rc = reduce_on(R.comm_stream)) return rc;
     HIPCK(c, rank, hipEventRecord(R.ev_comm[ci], R.comm_stream));
     return 0;
 }
@@ -866,7 +1093,7 @@ int pplhip_run(pplhip_ctx* c, int rank, int cache_prefill) {
     const int hd = d.hidden_dim;
     const int64_t nb_decode = std::min<int64_t>(std::max<int64_t>(R.decoding_batches, 0), B);
     const int threads = c->o.decoding_attn_tpb == 512 ? 512 : 256;
-    const bool comm = R.comm != nullptr;
+    const bool comm = c->tp_on;
 
     // Tensor parallel: the step is cut at a request boundary into two chunks of about T/2 rows.  While RCCL reduces
     // the partial sums of one chunk on the communication stream, the compute stream runs the other chunk's block
@@ -926,7 +1153,14 @@ int pplhip_run(pplhip_ctx* c, int rank, int cache_prefill) {
             HIPCK(c, rank, hipEventRecord(R.ev_compute[0], s));
             HIPCK(c, rank, hipStreamWaitEvent(cs, R.ev_compute[0], 0));
         }
-        NCCLCK(c, rank, ncclAllGather(R.logits_local, R.logits_gather, (size_t)B * vl, ncclFloat32, R.comm, cs));
+        if (c->comm_mode == 2) {
+            HIPCK(c, rank, launch_p2p_allgather(cs, R.peers, R.global_rank, c->tp, R.logits_local, R.x_gather, (int64_t)B * vl * 4,
+                                                (int64_t)B * vl * 4, ++R.p2p_epoch, c->p2p_timeout_ticks, R.p2p_status));
+        } else if (R.comm) {
+            NCCLCK(c, rank, ncclAllGather(R.logits_local, R.logits_gather, (size_t)B * vl, ncclFloat32, R.comm, cs));
+        } else {  // world size 1 without a communicator cannot happen (tp_on implies one of the two)
+            return fail(c, rank, PPLHIP_OTHER_ERROR, "tensor-parallel step without collectives");
+        }
         if (ov) {
             HIPCK(c, rank, hipEventRecord(R.ev_comm[0], cs));
             HIPCK(c, rank, hipStreamWaitEvent(s, R.ev_comm[0], 0));
@@ -950,7 +1184,7 @@ int pplhip_sync(pplhip_ctx* c, int rank) {
     if (!c || rank < 0 || rank >= (int)c->ranks.size()) return PPLHIP_INVALID_VALUE;
     HIPCK(c, rank, hipSetDevice(c->ranks[rank].device));
     HIPCK(c, rank, hipStreamSynchronize(c->ranks[rank].stream));
-    return 0;
+    return p2p_check(c, rank);
 }
 
 int pplhip_copy_logits(pplhip_ctx* c, int rank, float* dst, int64_t batch) {
@@ -958,6 +1192,7 @@ int pplhip_copy_logits(pplhip_ctx* c, int rank, float* dst, int64_t batch) {
     Rank& R = c->ranks[rank];
     HIPCK(c, rank, hipSetDevice(R.device));
     HIPCK(c, rank, hipStreamSynchronize(R.stream));
+    if (int rc = p2p_check(c, rank)) return rc;
     HIPCK(c, rank, hipMemcpy(dst, R.logits, (size_t)batch * c->d.vocab_size * 4, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -998,7 +1233,7 @@ int pplhip_sample(pplhip_ctx* c, const float* logits_device, const pplhip_sample
     HIPCK(c, 0, hipMemcpyAsync(output_host, R.d_tokout, B * 4, hipMemcpyDeviceToHost, s));
     HIPCK(c, 0, hipMemcpyAsync(logprob_host, R.d_lp, B * 4, hipMemcpyDeviceToHost, s));
     HIPCK(c, 0, hipStreamSynchronize(s));  // the step's only host<->device synchronisation (post_processor.cc:212)
-    return 0;
+    return p2p_check(c, 0);
 }
 
 int pplhip_penalty(pplhip_ctx* c, float* logits_device, const pplhip_penalty_args* a) {

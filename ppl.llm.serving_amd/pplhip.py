@@ -14,6 +14,8 @@ import numpy as np
 _DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_DIR, "csrc", "libpplhip.so")
 UNIQUE_ID_BYTES = 128
+IPC_HANDLE_BYTES = 64
+COMM_NONE, COMM_RCCL, COMM_P2P = 0, 1, 2
 _LIB = None
 
 STATUS = {0: "SUCCESS", -1: "OTHER_ERROR", -2: "INVALID_VALUE", -3: "OUT_OF_MEMORY", -4: "DEVICE_RUNTIME_ERROR",
@@ -70,6 +72,7 @@ class KvView(C.Structure):
 # every symbol include/pplhip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "pplhip_version", "pplhip_device_count", "pplhip_get_unique_id", "pplhip_init", "pplhip_destroy",
+    "pplhip_comm_export", "pplhip_comm_connect", "pplhip_comm_mode",
     "pplhip_last_error", "pplhip_rank_load", "pplhip_rank_set_tensor", "pplhip_rank_init_synthetic",
     "pplhip_kv_block_bytes", "pplhip_kv_capacity", "pplhip_kv_alloc", "pplhip_kv_ptrs", "pplhip_kv_read",
     "pplhip_kv_write", "pplhip_kv_fill_synthetic", "pplhip_set_inputs", "pplhip_run", "pplhip_logits", "pplhip_copy_logits", "pplhip_sync",
@@ -96,6 +99,9 @@ def lib():
         L.pplhip_init.argtypes = [C.POINTER(ModelDesc), C.POINTER(Opts), C.POINTER(vp)]
         L.pplhip_destroy.argtypes = [vp]
         L.pplhip_destroy.restype = None
+        L.pplhip_comm_export.argtypes = [vp, C.c_int, vp]
+        L.pplhip_comm_connect.argtypes = [vp, vp]
+        L.pplhip_comm_mode.argtypes = [vp]
         L.pplhip_rank_load.argtypes = [vp, C.c_int, C.c_char_p]
         L.pplhip_rank_set_tensor.argtypes = [vp, C.c_int, C.c_char_p, vp, u64]
         L.pplhip_rank_init_synthetic.argtypes = [vp, C.c_int, u64]
@@ -213,6 +219,20 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    # tensor-parallel collectives (one process per GPU: export -> all-gather by the launcher -> connect)
+    def comm_export(self, rank=0):
+        buf = (C.c_uint8 * IPC_HANDLE_BYTES)()
+        self._ck(lib().pplhip_comm_export(self.h, rank, buf), rank, "comm_export")
+        return bytes(buf)
+
+    def comm_connect(self, all_handles):
+        blob = b"".join(all_handles)
+        buf = C.create_string_buffer(blob, len(blob))
+        self._ck(lib().pplhip_comm_connect(self.h, buf), -1, "comm_connect")
+
+    def comm_mode(self):
+        return lib().pplhip_comm_mode(self.h)
 
     # weights
     def set_tensor(self, rank, name, arr):

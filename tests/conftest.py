@@ -4,6 +4,11 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# tests/test_gpu_tp.py emulates a whole tensor-parallel group on ONE device: up to 8 ranks = 16 streams whose kernels wait
+# for each other.  ROCm multiplexes a process's streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues; two ranks
+# sharing a queue would serialise behind each other's spinning collectives.  (Must be set before the HIP runtime starts;
+# irrelevant on a real node where every rank has its own device.)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

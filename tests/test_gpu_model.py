@@ -11,6 +11,7 @@ import pytest
 
 from oracle import ref
 from tests.conftest import load_pplhip
+from tests.parity import record_err
 from tests.test_oracle_hf import desc_from_meta, load_fixture
 
 pytestmark = pytest.mark.gpu
@@ -62,10 +63,13 @@ def generate_both(m, ctx, models, desc, prompts, steps, max_tokens):
     return res
 
 
-def check_steps(res, k):
+def check_steps(res, k, name=None):
+    if name is None:
+        name = os.environ.get("PYTEST_CURRENT_TEST", "?").split("::")[-1].split(" ")[0]
     for s, (got, want, gtok, wtok, glp, wlp) in enumerate(res):
         tol = 1e-3 * k * max(1.0, np.abs(want).max())
         err = np.abs(got - want).max()
+        record_err(name, err / max(1.0, np.abs(want).max()), 1e-3 * k)
         assert err <= tol, (s, err, tol)
         srt = np.sort(want, -1)
         safe = (srt[:, -1] - srt[:, -2]) > 2 * tol

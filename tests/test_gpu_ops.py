@@ -87,7 +87,9 @@ def test_rmsnorm(hidden, skip):
 @pytest.mark.parametrize("wq", [0, 8, 4])
 @pytest.mark.parametrize("M,N,K", [(1, 128, 128), (5, 384, 256), (130, 320, 128), (64, 512, 1376), (257, 1024, 4096),
                                    (33, 1024, 704), (2100, 1284, 512), (100, 384, 4096), (200, 260, 2048), (1024, 1536, 1024),
-                                   (4100, 1092, 256)])   # M >= 4096: the 256 x 256 tile kernel (prefill steps)
+                                   (4100, 1092, 256),    # M >= 4096: the 256 x 256 tile kernel (prefill steps)
+                                   # per-rank shapes of BASELINE configs 3 / 4: 13B/TP2 wqkv and w2, 70B/TP8 wqkv, wo-like and w2
+                                   (300, 7680, 5120), (300, 5120, 6912), (256, 1280, 8192), (64, 8192, 1024), (130, 8192, 3584)])
 def test_linear(wq, M, N, K):
     m = load_pplhip()
     if wq == 4 and K % 128:
@@ -298,6 +300,46 @@ def test_attention_prefill_and_mixed(quant, layout, mode, H, Hkv, D):
     # prefill path: K/V dequantised to fp16 and P rounded to fp16 before the MFMAs: 4e-3 relative to |V|max
     vmax = 3.0 if not quant else 0.03 * 127
     close_f16(out.cpu().numpy(), want, rel=4e-3, abs_=4e-3 * vmax)
+
+
+LONG_CASES = [  # (new tokens, cached tokens) per request, (H, Hkv)
+    ([1024], [0], (2, 2)), ([2048, 5], [0, 0], (2, 2)), ([4096], [0], (8, 1)), ([1500, 700], [300, 4000], (2, 2)),
+    # BASELINE config 5: 2048 new tokens behind a 6144-token cached prefix (benchmark_prefix_cache_offline shape)
+    ([2048], [6144], (2, 2)), ([2048], [6144], (8, 1)),
+]
+
+
+@pytest.mark.parametrize("quant", [8, 0])
+@pytest.mark.parametrize("seqlens,start,heads", LONG_CASES)
+def test_attention_long_prefill_and_cache_prefill(quant, seqlens, start, heads):
+    """prefill / cache-prefill attention against the oracle at 1k .. 8k keys (dozens of 128-key tiles per query tile):
+    causal wave skipping, the mask-only-on-diagonal-tiles rule, the conditional rescale across many tiles and the
+    8192-key cache-prefill of the prefix-cache benchmark -- paged (16-token pages, shuffled), int8 and fp16 KV."""
+    m = load_pplhip()
+    H, Hkv = heads
+    D = 128
+    case = KvCase(m, H, Hkv, D, L=1, layer=0, quant=quant, layout=3, mode=1, seqlens=seqlens, start_pos=start,
+                  seed=len(seqlens) + quant + H, page_size=16, decoding_batches=0)
+    rng = np.random.RandomState(17)
+    if quant:
+        case.cache[:] = rng.randint(-127, 128, size=case.cache.size).astype(np.int8)
+        case.scale[:] = f16(0.02 * (0.5 + rng.rand(case.scale.size)))
+    else:
+        case.cache[:] = f16(rng.randn(case.cache.size))
+    q32 = case.ref_write()
+    want = case.ref_attention(q32)
+    dq = dev(q32.astype(np.float16))
+    dcache, dscale = dev(case.cache), (dev(case.scale) if quant else None)
+    v = case.view(dcache, dscale)
+    out = torch.zeros((case.T, H * D), dtype=torch.float16, device="cuda")
+    ck(m.lib().pplhip_op_attention(None, dq.data_ptr(), C.byref(v), dev(case.seq_starts).data_ptr(),
+                                   dev(case.start_pos).data_ptr(), dev(case.cache_idx).data_ptr(), case.max_pages, case.B,
+                                   case.T, 0, case.max_seq_len, case.max_kv_len, H, 1, None, 0, out.data_ptr()))
+    got = out.cpu().numpy().astype(np.float32)
+    vmax = 3.0 if not quant else 0.03 * 127
+    from tests.parity import record_err
+    record_err(f"attn_long_q{quant}_{seqlens}_{start}_{heads}", float(np.abs(got - want).max()) / vmax, 4e-3)
+    close_f16(got, want, rel=4e-3, abs_=4e-3 * vmax)
 
 
 def test_sampler_greedy_and_topk():
