@@ -3,22 +3,29 @@
 // bound by that link; here every rank talks to all its peers at once, so a 8 MiB all-reduce at N = 8 puts 1 MiB on each
 // of the 7 links per phase (~14 us against ~96 us for a ring).
 //
-//   all-reduce(sum) of fp16[count], in place in a SYMMETRIC buffer (same offset in every rank's exchange region):
+//   all-reduce(sum) of fp16[count] held at the same offset of every rank's exchange region, two-shot, PULL only:
 //     1. start barrier  : block b of every rank tells block b of every peer "my partial sums are complete" (the kernel is
 //                         stream-ordered after the GEMM that produced them) and waits for the same from all of them;
-//     2. reduce-scatter : rank r owns the r-th 1/N of the buffer: it PULLS that slice from every rank (peer reads over the
+//     2. reduce-scatter : rank r owns the r-th 1/N of the buffer: it reads that slice of every rank (peer reads over the
 //                         rank's N-1 links in parallel), adds in fp32 in rank order 0..N-1 -- one rounding to fp16, the
-//                         oracle's arithmetic (oracle/llama_ref.c ref_forward) -- and
-//     3. all-gather     : PUSHES the reduced slice into the same place of every rank's buffer (peer writes);
-//     4. end barrier    : block b waits until block b of every peer has finished writing.
-//   all-gather of the fp32 logits shards: every rank pushes its [B, V/N] block into slot `me` of every peer's gather
-//   buffer between a start and an end barrier.
+//                         oracle's arithmetic (oracle/llama_ref.c ref_forward) -- and stores the result in its OWN scratch
+//                         slice (exchange region, double-buffered by epoch parity);
+//     3. middle barrier : "my reduced slice is published, and I am done reading your partial sums";
+//     4. all-gather     : every rank reads the N reduced slices from their owners' scratch and writes the whole result over
+//                         its own buffer with ordinary stores -- a kernel's plain output, consumed by the next kernel like
+//                         any other.  No end barrier: a rank's scratch is rewritten two collectives later, behind two more
+//                         start barriers that every peer only passes after leaving this kernel.
+//   Peers never WRITE each other's data, only flag words: a remote store into memory that a later local kernel reads with
+//   ordinary loads would depend on that GPU's caches holding no older copy of the line.
+//   all-gather of the fp32 logits shards: start barrier, every rank reads every peer's shard (published in the exchange
+//   region by a local copy) into its own gather buffer.
 //
-// Visibility rules this relies on (nothing else): the exchange region is allocated UNCACHED (hipDeviceMallocUncached: no
-// L2 residency on either side); every access a peer must see or that reads a peer's data is a SYSTEM-scope relaxed atomic
-// (global_load/store ... sc0 sc1: misses / writes through every cache level); every writing wave drains its stores
-// (s_waitcnt vmcnt(0)) before the block's flag is raised; flags are 32-bit epochs compared with wrap-safe >=, one word per
-// (block, source rank), so nothing is ever reset and a late reader of epoch e is not confused by e + 1.
+// Visibility rules this relies on (nothing else): the exchange region is FINE-GRAINED device memory (coherent between
+// devices at system scope; pplhip.cc explains why not "uncached");
+// every access that reads a peer's data or publishes data for a peer is a SYSTEM-scope relaxed atomic (global_load/store
+// ... sc0 sc1: misses / writes through every cache level); every wave that published data drains its stores (s_waitcnt
+// vmcnt(0)) before the block's flag is raised; flags are 32-bit epochs compared with wrap-safe >=, one word per (barrier
+// kind, block, source rank), so nothing is ever reset and a late reader of epoch e is not confused by e + 1.
 // All spins are bounded (s_memrealtime): on a timeout the kernel raises a status word in host memory and returns instead of
 // hanging the GPU; the runtime turns that into an error at the step's synchronisation point.
 #include "kernels.h"
@@ -72,41 +79,65 @@ __device__ __forceinline__ void add4(float* acc, u64 v) {
 
 // N > 0: compile-time rank count (2, 4, 8); N == 0: any n <= P2P_MAX_RANKS
 template <int N>
-__global__ __launch_bounds__(512) void p2p_allreduce_kernel(P2pPeers peers, int me, int n_rt, size_t data_off, int64_t granules,
-                                                            uint32_t epoch, u64 timeout_ticks, uint32_t* status) {
+__global__ __launch_bounds__(512) void p2p_allreduce_kernel(P2pPeers peers, int me, int n_rt, size_t data_off, size_t scratch_off,
+                                                            int64_t granules, uint32_t epoch, u64 timeout_ticks, uint32_t* status) {
     const int n = N > 0 ? N : n_rt;
-    cross_rank_barrier<false>(peers, me, n, P2P_FLAGS_START, epoch, timeout_ticks, status);
-    const int64_t per = (granules + n - 1) / n;
-    const int64_t lo = per * me, hi = (lo + per < granules) ? lo + per : granules;
     constexpr int MAXN = N > 0 ? N : P2P_MAX_RANKS;
-    for (int64_t g = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < hi; g += (int64_t)gridDim.x * blockDim.x) {
-        u64 v[MAXN];
+    const int64_t per = (granules + n - 1) / n;  // slice of rank r: granules [r * per, min((r + 1) * per, granules))
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+    cross_rank_barrier<false>(peers, me, n, P2P_FLAGS_START, epoch, timeout_ticks, status);
+    {   // reduce-scatter into my scratch slice
+        const int64_t lo = per * me, hi = (lo + per < granules) ? lo + per : granules;
+        u64* mine = reinterpret_cast<u64*>(peers.base[me] + scratch_off);
+        for (int64_t g = lo + tid; g < hi; g += nthr) {
+            u64 v[MAXN];
 #pragma unroll
-        for (int r = 0; r < MAXN; ++r)
-            if (r < n) v[r] = ld_sys(reinterpret_cast<const u64*>(peers.base[r] + data_off) + g);
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < MAXN; ++r)
+                if (r < n) v[r] = ld_sys(reinterpret_cast<const u64*>(peers.base[r] + data_off) + g);
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < MAXN; ++r)
-            if (r < n) add4(acc, v[r]);  // rank order 0 .. n-1 on every element: all ranks hold the same bits afterwards
-        const h4 o = {to_h(acc[0]), to_h(acc[1]), to_h(acc[2]), to_h(acc[3])};
-        const u64 ov = __builtin_bit_cast(u64, o);
-#pragma unroll
-        for (int r = 0; r < MAXN; ++r)
-            if (r < n) st_sys(reinterpret_cast<u64*>(peers.base[r] + data_off) + g, ov);
+            for (int r = 0; r < MAXN; ++r)
+                if (r < n) add4(acc, v[r]);  // rank order 0 .. n-1 on every element: one result for the whole group
+            const h4 o = {to_h(acc[0]), to_h(acc[1]), to_h(acc[2]), to_h(acc[3])};
+            st_sys(mine + (g - lo), __builtin_bit_cast(u64, o));
+        }
     }
-    cross_rank_barrier<true>(peers, me, n, P2P_FLAGS_END, epoch, timeout_ticks, status);
+    cross_rank_barrier<true>(peers, me, n, P2P_FLAGS_MID, epoch, timeout_ticks, status);
+    {   // all-gather: slice r from rank r's scratch -> my buffer (ordinary stores)
+        u64* out = reinterpret_cast<u64*>(peers.base[me] + data_off);
+        for (int64_t g = tid; g < per; g += nthr) {
+            u64 v[MAXN];
+#pragma unroll
+            for (int r = 0; r < MAXN; ++r)
+                if (r < n && per * r + g < granules) v[r] = ld_sys(reinterpret_cast<const u64*>(peers.base[r] + scratch_off) + g);
+#pragma unroll
+            for (int r = 0; r < MAXN; ++r)
+                if (r < n && per * r + g < granules) out[per * r + g] = v[r];
+        }
+    }
 }
 
-// every rank pushes src[granules] (its own, ordinary memory) into slot `me` (slot_granules apart) of every rank's gather buffer
-__global__ __launch_bounds__(512) void p2p_allgather_kernel(P2pPeers peers, int me, int n, const u64* __restrict__ src, size_t dst_off,
-                                                            int64_t granules, int64_t slot_granules, uint32_t epoch,
-                                                            u64 timeout_ticks, uint32_t* status) {
+// logits shards: rows x row_granules 8-byte granules at src_off of every rank's region (rank r's [rows, V/n] block)
+// -> columns [r * row_granules, (r + 1) * row_granules) of my [rows, dst_row_granules] matrix (ordinary local memory)
+__global__ __launch_bounds__(512) void p2p_allgather_kernel(P2pPeers peers, int me, int n, size_t src_off, u64* __restrict__ dst,
+                                                            int64_t rows, int64_t row_granules, int64_t dst_row_granules,
+                                                            uint32_t epoch, u64 timeout_ticks, uint32_t* status) {
     cross_rank_barrier<false>(peers, me, n, P2P_FLAGS_START, epoch, timeout_ticks, status);
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < granules; g += (int64_t)gridDim.x * blockDim.x) {
-        const u64 v = src[g];
-        for (int r = 0; r < n; ++r) st_sys(reinterpret_cast<u64*>(peers.base[r] + dst_off) + (int64_t)me * slot_granules + g, v);
+    const int64_t total = rows * row_granules;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = g / row_granules, col = g - row * row_granules;
+        for (int r = 0; r < n; ++r)
+            dst[row * dst_row_granules + (int64_t)r * row_granules + col] = ld_sys(reinterpret_cast<const u64*>(peers.base[r] + src_off) + g);
     }
-    cross_rank_barrier<true>(peers, me, n, P2P_FLAGS_END, epoch, timeout_ticks, status);
+}
+
+// self-test inputs, produced the way the real inputs are: by a kernel on the rank's stream (exactly representable values
+// whose sums over <= 8 ranks are exact in fp16)
+__device__ __forceinline__ float p2p_pat(int64_t i, int g, int round) { return (float)((int)((i * 7 + g * 13 + round * 5) % 64) - 32) * 0.25f; }
+__global__ __launch_bounds__(256) void p2p_pattern_kernel(uint16_t* __restrict__ halfs, int64_t cnt, float* __restrict__ floats, int64_t gcnt,
+                                                          int g, int round) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * 256) halfs[i] = f2h(p2p_pat(i, g, round));
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < gcnt; i += (int64_t)gridDim.x * 256) floats[i] = p2p_pat(i, g, round + 2);
 }
 
 int grid_for(int64_t granules_per_rank) {
@@ -121,26 +152,32 @@ int grid_for(int64_t granules_per_rank) {
 
 }  // namespace
 
-hipError_t launch_p2p_allreduce(hipStream_t s, const P2pPeers& peers, int me, int n, size_t data_off, int64_t count, uint32_t epoch,
-                                uint64_t timeout_ticks, uint32_t* status) {
-    if (n < 2 || n > P2P_MAX_RANKS || count % 4 || data_off % 8) return hipErrorInvalidValue;
-    if (count == 0) return hipSuccess;
-    const int64_t granules = count / 4;
-    const dim3 grid(grid_for((granules + n - 1) / n)), block(512);
-    if (n == 2) hipLaunchKernelGGL(p2p_allreduce_kernel<2>, grid, block, 0, s, peers, me, n, data_off, granules, epoch, (u64)timeout_ticks, status);
-    else if (n == 4) hipLaunchKernelGGL(p2p_allreduce_kernel<4>, grid, block, 0, s, peers, me, n, data_off, granules, epoch, (u64)timeout_ticks, status);
-    else if (n == 8) hipLaunchKernelGGL(p2p_allreduce_kernel<8>, grid, block, 0, s, peers, me, n, data_off, granules, epoch, (u64)timeout_ticks, status);
-    else hipLaunchKernelGGL(p2p_allreduce_kernel<0>, grid, block, 0, s, peers, me, n, data_off, granules, epoch, (u64)timeout_ticks, status);
+float p2p_pattern_value(int64_t i, int g, int round) { return (float)((int)((i * 7 + g * 13 + round * 5) % 64) - 32) * 0.25f; }
+
+hipError_t launch_p2p_pattern(hipStream_t s, uint16_t* halfs, int64_t cnt, float* floats, int64_t gcnt, int g, int round) {
+    hipLaunchKernelGGL(p2p_pattern_kernel, dim3(256), dim3(256), 0, s, halfs, cnt, floats, gcnt, g, round);
     return hipGetLastError();
 }
 
-hipError_t launch_p2p_allgather(hipStream_t s, const P2pPeers& peers, int me, int n, const void* src, size_t dst_off, int64_t bytes,
-                                int64_t slot_bytes, uint32_t epoch, uint64_t timeout_ticks, uint32_t* status) {
-    if (n < 2 || n > P2P_MAX_RANKS || bytes % 8 || slot_bytes % 8 || dst_off % 8) return hipErrorInvalidValue;
-    if (bytes == 0) return hipSuccess;
-    const dim3 grid(grid_for(bytes / 8)), block(512);
-    hipLaunchKernelGGL(p2p_allgather_kernel, grid, block, 0, s, peers, me, n, reinterpret_cast<const u64*>(src), dst_off, bytes / 8,
-                       slot_bytes / 8, epoch, (u64)timeout_ticks, status);
+hipError_t launch_p2p_allreduce(hipStream_t s, const P2pPeers& peers, int me, int n, size_t data_off, size_t scratch_off, int64_t count,
+                                uint32_t epoch, uint64_t timeout_ticks, uint32_t* status) {
+    if (n < 2 || n > P2P_MAX_RANKS || count % 4 || data_off % 8 || scratch_off % 8) return hipErrorInvalidValue;
+    if (count == 0) return hipSuccess;
+    const int64_t granules = count / 4;
+    const dim3 grid(grid_for((granules + n - 1) / n)), block(512);
+#define AR(NN) hipLaunchKernelGGL(p2p_allreduce_kernel<NN>, grid, block, 0, s, peers, me, n, data_off, scratch_off, granules, epoch, (u64)timeout_ticks, status)
+    if (n == 2) AR(2); else if (n == 4) AR(4); else if (n == 8) AR(8); else AR(0);
+#undef AR
+    return hipGetLastError();
+}
+
+hipError_t launch_p2p_allgather(hipStream_t s, const P2pPeers& peers, int me, int n, size_t src_off, void* dst, int64_t rows,
+                                int64_t row_bytes, int64_t dst_row_bytes, uint32_t epoch, uint64_t timeout_ticks, uint32_t* status) {
+    if (n < 2 || n > P2P_MAX_RANKS || row_bytes % 8 || dst_row_bytes % 8 || src_off % 8) return hipErrorInvalidValue;
+    if (rows == 0 || row_bytes == 0) return hipSuccess;
+    const dim3 grid(grid_for(rows * row_bytes / 8)), block(512);
+    hipLaunchKernelGGL(p2p_allgather_kernel, grid, block, 0, s, peers, me, n, src_off, reinterpret_cast<u64*>(dst), rows, row_bytes / 8,
+                       dst_row_bytes / 8, epoch, (u64)timeout_ticks, status);
     return hipGetLastError();
 }
 

@@ -62,17 +62,23 @@ constexpr int P2P_MAX_RANKS = 8;
 constexpr int P2P_MAX_BLOCKS = 64;
 // exchange-region layout (bytes, identical on every rank): flag words first, data buffers after P2P_DATA_START
 constexpr size_t P2P_FLAGS_START = 0;                                         // uint32 [P2P_MAX_BLOCKS][P2P_MAX_RANKS]
-constexpr size_t P2P_FLAGS_END = (size_t)P2P_MAX_BLOCKS * P2P_MAX_RANKS * 4;  // uint32 [P2P_MAX_BLOCKS][P2P_MAX_RANKS]
+constexpr size_t P2P_FLAGS_MID = (size_t)P2P_MAX_BLOCKS * P2P_MAX_RANKS * 4;  // uint32 [P2P_MAX_BLOCKS][P2P_MAX_RANKS]
 constexpr size_t P2P_DATA_START = 8192;
 struct P2pPeers {
     char* base[P2P_MAX_RANKS];  // exchange region of every rank as mapped in this process (base[me] is the local one)
 };
-// in-place all-reduce(sum) of fp16[count] at byte offset data_off of every rank's region (count % 4 == 0)
-hipError_t launch_p2p_allreduce(hipStream_t s, const P2pPeers& peers, int me, int n, size_t data_off, int64_t count, uint32_t epoch,
-                                uint64_t timeout_ticks, uint32_t* status);
-// src[bytes] (ordinary local memory) -> bytes at dst_off + me * slot_bytes of every rank's region
-hipError_t launch_p2p_allgather(hipStream_t s, const P2pPeers& peers, int me, int n, const void* src, size_t dst_off, int64_t bytes,
-                                int64_t slot_bytes, uint32_t epoch, uint64_t timeout_ticks, uint32_t* status);
+// all-reduce(sum) of fp16[count] at byte offset data_off of every rank's region (count % 4 == 0); scratch_off: a region
+// offset with room for ceil(count / n) fp16 that no other collective in flight uses
+hipError_t launch_p2p_allreduce(hipStream_t s, const P2pPeers& peers, int me, int n, size_t data_off, size_t scratch_off, int64_t count,
+                                uint32_t epoch, uint64_t timeout_ticks, uint32_t* status);
+// rows x row_bytes at src_off of every rank's region (rank r's column block) -> columns [r * row_bytes, ...) of the local
+// [rows, dst_row_bytes] matrix dst (ordinary memory)
+hipError_t launch_p2p_allgather(hipStream_t s, const P2pPeers& peers, int me, int n, size_t src_off, void* dst, int64_t rows,
+                                int64_t row_bytes, int64_t dst_row_bytes, uint32_t epoch, uint64_t timeout_ticks, uint32_t* status);
+
+// self-test patterns: halfs[i] = value(i, g, round), floats[i] = value(i, g, round + 2)
+float p2p_pattern_value(int64_t i, int g, int round);
+hipError_t launch_p2p_pattern(hipStream_t s, uint16_t* halfs, int64_t cnt, float* floats, int64_t gcnt, int g, int round);
 
 // ---- k_sample.hip -----------------------------------------------------------------------------
 hipError_t launch_sample_greedy(hipStream_t s, const float* logits, const float* temperatures, int batch, int vocab,

@@ -101,10 +101,11 @@ struct Rank {
     float *d_rep = nullptr, *d_pres = nullptr, *d_freq = nullptr, *d_ptemp = nullptr;
     float* h_rand = nullptr;  // pinned
 
-    // exchange region of the direct collectives (k_comm.hip): uncached, peer-mapped; holds the flag words and the buffers
+    // exchange region of the direct collectives (k_comm.hip): fine-grained, peer-mapped; holds the flag words and the buffers
     // the collectives work in place on (part, part2) or push into (logits_gather)
     char* xbase = nullptr;
-    size_t xbytes = 0, x_part = 0, x_part2 = 0, x_gather = 0;  // byte offsets inside the region
+    size_t xbytes = 0, x_part = 0, x_part2 = 0, x_scratch[2] = {0, 0}, x_local = 0;  // byte offsets inside the region
+    uint32_t ar_count = 0;              // all-reduces issued (scratch double buffer)
     P2pPeers peers{};
     bool peer_ipc[P2P_MAX_RANKS] = {};  // peers.base[g] came from hipIpcOpenMemHandle (closed on destroy)
     uint32_t p2p_epoch = 0;
@@ -266,34 +267,35 @@ int p2p_unavailable(pplhip_ctx* c, int rank, const std::string& why) {
     return 0;
 }
 
-// Runs both collectives twice on known patterns on every local rank (all ranks of the group do this at the same time,
+// Runs both collectives four times on changing patterns on every local rank (all ranks of the group do this at the same time,
 // in this process or in others) and compares with the exact answer.  Every rank then learns whether ALL ranks passed
 // (one RCCL all-reduce when a communicator exists); only then comm_mode becomes 2.
 int p2p_selftest(pplhip_ctx* c) {
     const int n = (int)c->ranks.size(), tp = c->tp, hd = c->d.hidden_dim;
     const int64_t cnt = std::min<int64_t>((int64_t)1 << 20, c->ranks[0].cap_T * (int64_t)hd) / 4 * 4;
-    const int64_t gcnt = std::min<int64_t>((int64_t)1 << 18, c->ranks[0].cap_B * (int64_t)c->vocab_local) / 2 * 2;  // floats
+    // the gather test: every rank's [grows, gcols] fp32 block -> [grows, gcols * tp]
+    const int64_t gcols = c->vocab_local / 2 * 2, grows = std::min<int64_t>(c->ranks[0].cap_B, std::max<int64_t>(1, ((int64_t)1 << 18) / gcols));
+    const int64_t gcnt = grows * gcols;
     const char* e = getenv("PPLHIP_P2P_SELFTEST_MS");
     const uint64_t ticks = (uint64_t)(e ? std::max(1, atoi(e)) : 10000) * 100000ull;
-    auto pat = [](int64_t i, int g, int round) { return (float)((int)((i * 7 + g * 13 + round * 5) % 64) - 32) * 0.25f; };
+    auto pat = [](int64_t i, int g, int round) { return p2p_pattern_value(i, g, round); };
     bool ok = true;
     std::string why;
     std::vector<uint16_t> hbuf(cnt);
     std::vector<float> gbuf(gcnt), gall;
-    for (int round = 0; round < 2 && ok; ++round) {
+    for (int round = 0; round < 4 && ok; ++round) {
         for (int r = 0; r < n; ++r) {
             Rank& R = c->ranks[r];
             HIPCK(c, r, hipSetDevice(R.device));
-            for (int64_t i = 0; i < cnt; ++i) hbuf[i] = __builtin_bit_cast(uint16_t, (_Float16)pat(i, R.global_rank, round));
-            for (int64_t i = 0; i < gcnt; ++i) gbuf[i] = pat(i, R.global_rank, round + 2);
-            HIPCK(c, r, hipMemcpy(R.part, hbuf.data(), cnt * 2, hipMemcpyHostToDevice));
-            HIPCK(c, r, hipMemcpy(R.logits_local, gbuf.data(), gcnt * 4, hipMemcpyHostToDevice));
+            // inputs are written by a kernel on the rank's stream, like the partial sums and logits shards of a real step
+            HIPCK(c, r, launch_p2p_pattern(R.stream, R.part, cnt, R.logits_local, gcnt, R.global_rank, round));
         }
         for (int r = 0; r < n; ++r) {
             Rank& R = c->ranks[r];
             HIPCK(c, r, hipSetDevice(R.device));
-            HIPCK(c, r, launch_p2p_allreduce(R.stream, R.peers, R.global_rank, tp, R.x_part, cnt, ++R.p2p_epoch, ticks, R.p2p_status));
-            HIPCK(c, r, launch_p2p_allgather(R.stream, R.peers, R.global_rank, tp, R.logits_local, R.x_gather, gcnt * 4, gcnt * 4,
+            HIPCK(c, r, launch_p2p_allreduce(R.stream, R.peers, R.global_rank, tp, R.x_part, R.x_scratch[R.ar_count++ & 1], cnt, ++R.p2p_epoch,
+                                             ticks, R.p2p_status));
+            HIPCK(c, r, launch_p2p_allgather(R.stream, R.peers, R.global_rank, tp, R.x_local, R.logits, grows, gcols * 4, (int64_t)gcols * 4 * tp,
                                              ++R.p2p_epoch, ticks, R.p2p_status));
         }
         for (int r = 0; r < n && ok; ++r) {
@@ -305,13 +307,33 @@ int p2p_selftest(pplhip_ctx* c) {
             for (int64_t i = 0; i < cnt && ok; ++i) {
                 float want = 0.f;
                 for (int g = 0; g < tp; ++g) want += pat(i, g, round);
-                if ((float)__builtin_bit_cast(_Float16, hbuf[i]) != want) { ok = false; why = "all-reduce mismatch at element " + std::to_string(i); }
+                if ((float)__builtin_bit_cast(_Float16, hbuf[i]) != want) {
+                    ok = false;
+                    int64_t nbad = 0, last = i;
+                    for (int64_t j = i; j < cnt; ++j) {
+                        float w2 = 0.f;
+                        for (int g = 0; g < tp; ++g) w2 += pat(j, g, round);
+                        if ((float)__builtin_bit_cast(_Float16, hbuf[j]) != w2) { ++nbad; last = j; }
+                    }
+                    why = "all-reduce mismatch: round " + std::to_string(round) + " rank " + std::to_string(R.global_rank) + " first " + std::to_string(i) +
+                          " last " + std::to_string(last) + " bad " + std::to_string(nbad) + "/" + std::to_string(cnt) + " got " +
+                          std::to_string((float)__builtin_bit_cast(_Float16, hbuf[i])) + " want " + std::to_string(want);
+                }
             }
             gall.resize((size_t)gcnt * tp);
-            HIPCK(c, r, hipMemcpy(gall.data(), R.logits_gather, gall.size() * 4, hipMemcpyDeviceToHost));
+            HIPCK(c, r, hipMemcpy(gall.data(), R.logits, gall.size() * 4, hipMemcpyDeviceToHost));
             for (int g = 0; g < tp && ok; ++g)
                 for (int64_t i = 0; i < gcnt && ok; ++i)
-                    if (gall[(size_t)g * gcnt + i] != pat(i, g, round + 2)) { ok = false; why = "all-gather mismatch in slot " + std::to_string(g); }
+                    if (gall[(size_t)(i / gcols) * gcols * tp + (size_t)g * gcols + i % gcols] != pat(i, g, round + 2)) {
+                        ok = false;
+                        int64_t nbad = 0, last = i;
+                        for (int64_t j = i; j < gcnt; ++j)
+                            if (gall[(size_t)(j / gcols) * gcols * tp + (size_t)g * gcols + j % gcols] != pat(j, g, round + 2)) { ++nbad; last = j; }
+                        why = "all-gather mismatch: round " + std::to_string(round) + " rank " + std::to_string(R.global_rank) + " block " + std::to_string(g) +
+                              " first " + std::to_string(i) + " last " + std::to_string(last) + " bad " + std::to_string(nbad) + "/" + std::to_string(gcnt) +
+                              " got " + std::to_string(gall[(size_t)(i / gcols) * gcols * tp + (size_t)g * gcols + i % gcols]) + " want " + std::to_string(pat(i, g, round + 2)) +
+                              " prev-round " + std::to_string(pat(i, g, round + 1));
+                    }
         }
     }
     // agreement: min over all ranks of the group
@@ -581,18 +603,28 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
             ALLOC(R.part, (uint64_t)cap_T * hd * 2);
             ALLOC(R.part2, (uint64_t)cap_T * hd * 2);
         } else {
-            // the buffers collectives touch live in ONE uncached allocation that peers map (k_comm.hip); RCCL works on them too
+            // the buffers collectives touch live in ONE fine-grained allocation that peers map (k_comm.hip); RCCL works on them too
             auto up = [](size_t v) { return (v + 4095) / 4096 * 4096; };
             R.x_part = P2P_DATA_START;
             R.x_part2 = R.x_part + up((size_t)cap_T * hd * 2);
-            R.x_gather = R.x_part2 + up((size_t)cap_T * hd * 2);
-            R.xbytes = R.x_gather + up((size_t)cap_B * d.vocab_size * 4);
-            hipError_t e = hipExtMallocWithFlags((void**)&R.xbase, R.xbytes, hipDeviceMallocUncached);
+            R.x_scratch[0] = R.x_part2 + up((size_t)cap_T * hd * 2);          // a rank's reduced slice: <= half the buffer (n >= 2)
+            R.x_scratch[1] = R.x_scratch[0] + up((size_t)cap_T * hd + 64);
+            R.x_local = R.x_scratch[1] + up((size_t)cap_T * hd + 64);
+            R.xbytes = R.x_local + up((size_t)cap_B * c->vocab_local * 4);
+            // FINE-GRAINED device memory: the kind HIP defines as coherent between devices at system scope (what RCCL puts its
+            // peer buffers in).  hipDeviceMallocUncached is NOT usable here: with several ranks on one MI355X a kernel reading
+            // a buffer that the previous kernel of another stream had just written through an uncached mapping saw stale data
+            // (profiles/probes/tp_matrix.sh: 8 bad steps of 36 and aborted runs, against 0 of 96 for fine-grained and plain
+            // memory).  PPLHIP_P2P_XALLOC=0 (plain) / 1 (uncached) exist for that probe only.
+            static const int xalloc = getenv("PPLHIP_P2P_XALLOC") ? atoi(getenv("PPLHIP_P2P_XALLOC")) : 2;
+            hipError_t e = xalloc == 0 ? hipMalloc((void**)&R.xbase, R.xbytes)
+                                       : hipExtMallocWithFlags((void**)&R.xbase, R.xbytes, xalloc == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
             if (e != hipSuccess) return fail(cp, r, PPLHIP_OUT_OF_MEMORY, std::string("exchange region: ") + hipGetErrorString(e));
             HIPCK(cp, r, hipMemset(R.xbase, 0, P2P_DATA_START));
             R.part = (uint16_t*)(R.xbase + R.x_part);
             R.part2 = (uint16_t*)(R.xbase + R.x_part2);
-            R.logits_gather = (float*)(R.xbase + R.x_gather);
+            R.logits_local = (float*)(R.xbase + R.x_local);
+            if (R.comm) ALLOC(R.logits_gather, (uint64_t)cap_B * d.vocab_size * 4);  // RCCL all-gather target
             HIPCK(cp, r, hipHostMalloc((void**)&R.p2p_status, 64, hipHostMallocMapped));
             *R.p2p_status = 0;
             ALLOC(R.d_flag, 64);
@@ -602,7 +634,6 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
         if (inter_p != c->inter) HIPCK(cp, r, hipMemset(R.act, 0, (uint64_t)cap_T * inter_p * 2));  // pad columns stay zero
         ALLOC(R.hn, (uint64_t)cap_B * hd * 2);
         ALLOC(R.logits, (uint64_t)cap_B * d.vocab_size * 4);
-        if (c->tp_on) ALLOC(R.logits_local, (uint64_t)cap_B * c->vocab_local * 4);
         R.attn_ws_bytes = attn_decode_workspace_bytes(cap_B, c->H, c->D, 32);
         ALLOC(R.attn_ws, R.attn_ws_bytes);
         R.gemm_ws_bytes = (size_t)8 * 256 * (size_t)std::max(std::max(2 * c->inter, (c->H + 2 * c->Hkv) * c->D), std::max(hd, c->vocab_local)) * sizeof(float);
@@ -1065,14 +1096,19 @@ static int chunk_allreduce(pplhip_ctx* c, int rank, uint16_t* buf, const Chunk& 
     uint16_t* p = buf + k.t0 * hd;
     auto reduce_on = [&](hipStream_t st) -> int {
         if (c->comm_mode == 2) {
-            HIPCK(c, rank, launch_p2p_allreduce(st, R.peers, R.global_rank, c->tp, (size_t)((char*)p - R.xbase), k.tn * hd, ++R.p2p_epoch,
-                                                c->p2p_timeout_ticks, R.p2p_status));
+            HIPCK(c, rank, launch_p2p_allreduce(st, R.peers, R.global_rank, c->tp, (size_t)((char*)p - R.xbase), R.x_scratch[R.ar_count++ & 1],
+                                                k.tn * hd, ++R.p2p_epoch, c->p2p_timeout_ticks, R.p2p_status));
         } else if (R.comm) {
             NCCLCK(c, rank, ncclAllReduce(p, p, (size_t)k.tn * hd, ncclFloat16, ncclSum, R.comm, st));
         }
         return 0;
     };
-    if (!overlapped) return reduce_on(R.stream);
+    static const int dbg = getenv("PPLHIP_TP_DEBUG") ? atoi(getenv("PPLHIP_TP_DEBUG")) : 0;
+    if (!overlapped || (dbg & 2)) return reduce_on(R.stream);
+    if (dbg & 1) {  // diagnosis: never re-record an event inside a step
+        hipEventCreateWithFlags(&R.ev_compute[ci], hipEventDisableTiming);
+        hipEventCreateWithFlags(&R.ev_comm[ci], hipEventDisableTiming);
+    }
     HIPCK(c, rank, hipEventRecord(R.ev_compute[ci], R.stream));
     HIPCK(c, rank, hipStreamWaitEvent(R.comm_stream, R.ev_compute[ci], 0));
     if (int rc = reduce_on(R.comm_stream)) return rc;
@@ -1114,6 +1150,7 @@ int pplhip_run(pplhip_ctx* c, int rank, int cache_prefill) {
         nck = 2;
     }
     const bool ov = nck == 2;
+    static const bool tpdbg2 = getenv("PPLHIP_TP_DEBUG") && (atoi(getenv("PPLHIP_TP_DEBUG")) & 2);  // diagnosis: chunks, but collectives in stream
     int split[2] = {1, 1};
     for (int i = 0; i < nck; ++i) split[i] = ck[i].nd > 0 ? decode_split(c, ck[i].nd, R.max_kv_len) : 1;
 
@@ -1124,18 +1161,18 @@ int pplhip_run(pplhip_ctx* c, int rank, int cache_prefill) {
     int rc;
     for (int l = 0; l < d.num_layers; ++l) {
         for (int i = 0; i < nck; ++i) {
-            if (ov && l > 0) HIPCK(c, rank, hipStreamWaitEvent(s, R.ev_comm[i], 0));  // part2 rows of chunk i are reduced
+            if (ov && l > 0 && !tpdbg2) HIPCK(c, rank, hipStreamWaitEvent(s, R.ev_comm[i], 0));  // part2 rows of chunk i are reduced
             if ((rc = layer_attention_part(c, rank, l, ck[i], pending, split[i], threads))) return rc;
             if (comm && (rc = chunk_allreduce(c, rank, R.part, ck[i], i, ov))) return rc;
         }
         for (int i = 0; i < nck; ++i) {
-            if (ov) HIPCK(c, rank, hipStreamWaitEvent(s, R.ev_comm[i], 0));            // part rows of chunk i are reduced
+            if (ov && !tpdbg2) HIPCK(c, rank, hipStreamWaitEvent(s, R.ev_comm[i], 0));            // part rows of chunk i are reduced
             if ((rc = layer_ffn_part(c, rank, l, ck[i]))) return rc;
             if (comm && (rc = chunk_allreduce(c, rank, R.part2, ck[i], i, ov))) return rc;
         }
         pending = R.part2;
     }
-    if (ov) for (int i = 0; i < nck; ++i) HIPCK(c, rank, hipStreamWaitEvent(s, R.ev_comm[i], 0));
+    if (ov && !tpdbg2) for (int i = 0; i < nck; ++i) HIPCK(c, rank, hipStreamWaitEvent(s, R.ev_comm[i], 0));
     // K11: last-token gather + final (Skip)RMSNorm (the last FFN output is folded into the residual of the gathered
     // rows only) + lm_head (+ all-gather of the vocab shards)
     HIPCK(c, rank, launch_rmsnorm(s, R.h, pending, R.norm, d.norm_eps, B, hd, R.d_seq, R.hn, nullptr));
@@ -1148,24 +1185,24 @@ int pplhip_run(pplhip_ctx* c, int rank, int cache_prefill) {
         HIPCK(c, rank, launch_linear(s, R.hn, R.output.w, nullptr, 0, 0, B, vl, hd, R.logits_local, vl, true, R.gemm_ws, R.gemm_ws_bytes));
         prof_end(R, &ev);
         // every collective of this communicator is issued on ONE stream (the communication stream when overlapping)
-        hipStream_t cs = ov ? R.comm_stream : s;
-        if (ov) {
+        hipStream_t cs = (ov && !tpdbg2) ? R.comm_stream : s;
+        if (ov && !tpdbg2) {
             HIPCK(c, rank, hipEventRecord(R.ev_compute[0], s));
             HIPCK(c, rank, hipStreamWaitEvent(cs, R.ev_compute[0], 0));
         }
-        if (c->comm_mode == 2) {
-            HIPCK(c, rank, launch_p2p_allgather(cs, R.peers, R.global_rank, c->tp, R.logits_local, R.x_gather, (int64_t)B * vl * 4,
-                                                (int64_t)B * vl * 4, ++R.p2p_epoch, c->p2p_timeout_ticks, R.p2p_status));
+        if (c->comm_mode == 2) {  // every rank pulls every shard straight into its [B, V] logits
+            HIPCK(c, rank, launch_p2p_allgather(cs, R.peers, R.global_rank, c->tp, R.x_local, R.logits, B, (int64_t)vl * 4,
+                                                (int64_t)d.vocab_size * 4, ++R.p2p_epoch, c->p2p_timeout_ticks, R.p2p_status));
         } else if (R.comm) {
             NCCLCK(c, rank, ncclAllGather(R.logits_local, R.logits_gather, (size_t)B * vl, ncclFloat32, R.comm, cs));
         } else {  // world size 1 without a communicator cannot happen (tp_on implies one of the two)
             return fail(c, rank, PPLHIP_OTHER_ERROR, "tensor-parallel step without collectives");
         }
-        if (ov) {
+        if (ov && !tpdbg2) {
             HIPCK(c, rank, hipEventRecord(R.ev_comm[0], cs));
             HIPCK(c, rank, hipStreamWaitEvent(s, R.ev_comm[0], 0));
         }
-        for (int r = 0; r < c->tp; ++r)
+        for (int r = 0; r < c->tp && c->comm_mode != 2; ++r)
             HIPCK(c, rank, hipMemcpy2DAsync(R.logits + (size_t)r * vl, (size_t)d.vocab_size * 4, R.logits_gather + (size_t)r * B * vl,
                                             (size_t)vl * 4, (size_t)vl * 4, B, hipMemcpyDeviceToDevice, s));
     }

@@ -181,8 +181,9 @@ class KvCase:
         self.cache = np.zeros(elems, dtype=np.int8 if quant else np.float16)
         self.scale = np.zeros(elems // 8, dtype=np.float16) if quant else None
         self.qkv = f16(rng.randn(self.T, (H + 2 * Hkv) * D))
-        self.rope = np.empty((4096, D), dtype=np.float32)
-        ref.lib().ref_build_rope_table(self.rope.ctypes.data, 4096, D, 10000.0)
+        npos = max(4096, self.max_kv_len + 1)   # the table must cover every position the case uses
+        self.rope = np.empty((npos, D), dtype=np.float32)
+        ref.lib().ref_build_rope_table(self.rope.ctypes.data, npos, D, 10000.0)
 
     def view(self, dcache, dscale):
         v = self.m.KvView()

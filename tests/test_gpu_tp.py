@@ -137,7 +137,7 @@ def check(name, res, k):
 
 
 @pytest.mark.parametrize("tp", [2, 4, 8])
-@pytest.mark.parametrize("mode,overlap", [(1, False), (0, True)])
+@pytest.mark.parametrize("mode,overlap", [(1, False), (0, True), (0, False), (1, True)])
 def test_tensor_parallel_group_on_one_device(monkeypatch, tp, mode, overlap):
     """tiny model, every tp: prefill + decode through all-reduce after wo / w2 and the logits all-gather, with the
     collectives on the compute stream and with the two-chunk schedule that puts them on the communication stream."""
@@ -189,9 +189,10 @@ def test_llama13b_tp2_rank_slices_w8a16():
                          weight_quant_bit=8, **dims)
     hd, inter, V, H, D = 5120, 13824, 32000, 40, 128
     rng = np.random.RandomState(13)
+    gen = np.random.default_rng(13)
 
     def w(n, k, amp):
-        return (rng.standard_normal((n, k), dtype=np.float32) * amp).astype(np.float16)
+        return (gen.standard_normal((n, k), dtype=np.float32) * amp).astype(np.float16)
 
     weights = {"tok_embeddings.weight": w(V, hd, 1.0), "norm.weight": f16(1 + 0.1 * rng.randn(hd)), "output.weight": w(V, hd, 0.02)}
     for l in range(2):
