@@ -141,8 +141,21 @@ def emit(obj):
     _JSON_OUT.flush()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` outside a launcher: become `python -m torch.distributed.run ... bench.py --gpus N ...`
+    (one process per GPU, the same command line the driver uses).  stdout stays the rank-0 JSON line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
-    claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
@@ -164,13 +177,14 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="no device work: exercises only the multi-process control plane (CPU test of the N>1 path)")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args.gpus)  # does not return
+    claim_stdout()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
         args.gpus = world
     dist = None
     if world > 1:
@@ -197,7 +211,8 @@ def main():
                        page_size=16 if args.cache_mode else 0,
                        weight_quant_bit=args.weight_quant, **mk)
     uid = None
-    if world > 1:
+    p2p_only = os.environ.get("PPLHIP_COMM") == "p2p"
+    if world > 1 and not p2p_only:
         box = [P.get_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         uid = box[0]
@@ -206,8 +221,18 @@ def main():
     elif os.environ.get("PPLHIP_FORCE_COMM"):
         uid = P.get_unique_id()  # single-GPU self-test of the RCCL path (world size 1: every collective is an identity)
     tp = args.emulate_tp if args.emulate_tp > 1 else world
+    # PPLHIP_BENCH_ONE_DEVICE=1 (tests): every rank on device 0 -- the multi-process plumbing (IPC handles, direct
+    # collectives) on a one-GPU box; needs PPLHIP_COMM=p2p because RCCL refuses two ranks on one device
+    dev = 0 if os.environ.get("PPLHIP_BENCH_ONE_DEVICE") else local_rank
     ctx = P.Context(desc, max_running_batch=B, max_tokens_per_step=max(8192, B), n_local_ranks=1, world_size=tp,
-                    rank_base=rank, device_ids=[local_rank], unique_id=uid, profiling=True, tpb=args.tpb)
+                    rank_base=rank, device_ids=[dev], unique_id=uid, profiling=True, tpb=args.tpb)
+    if world > 1 and os.environ.get("PPLHIP_COMM") != "rccl":
+        # one process per GPU: exchange the IPC handles of the exchange regions, then the collective self-test decides
+        # between the direct kernels and RCCL (the same decision on every rank)
+        handles = [None] * world
+        dist.all_gather_object(handles, ctx.comm_export(0))
+        ctx.comm_connect(handles)
+    comm_mode = {0: "none", 1: "rccl", 2: "direct xGMI kernels (two-shot, all links)"}[ctx.comm_mode()]
     ctx.init_synthetic(0, 1234)
     kv_tokens = B * total_len if args.cache_mode == 0 else B * ((total_len + 15) // 16) * 16
     cap = ctx.kv_capacity(0.94)
@@ -305,7 +330,7 @@ def main():
             "config": {"workload": f"{args.model} W{args.weight_quant or 16}A16 decode, batch {B}, kv_len {args.kv_len}"
                                    f"..{args.kv_len + K + W}, greedy top_k=1, cache_layout 3 / cache_mode {args.cache_mode}, "
                                    f"kv int{args.kv_quant or 16}", "global_batch": B, "seq_len": 1024,
-                       "parallelism": f"tp{world}", "layers": desc.num_layers},
+                       "parallelism": f"tp{world}", "layers": desc.num_layers, "collectives": comm_mode},
             "roofline": {"kernel": "attn_decode_kernel<8,128>" if args.kv_quant else "attn_decode_kernel<0,128>",
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "traffic": traffic,

@@ -398,24 +398,21 @@ REF_API void ref_linear_fwd(const ref_linear* l, const float* x, int64_t M, floa
                     _mm256_storeu_ps(wrow + k, _mm256_cvtepi32_ps(_mm256_cvtepi8_epi32(_mm_loadl_epi64((const __m128i*)(w + k)))));
                 for (; k < K; ++k) wrow[k] = (float)w[k];
             } else {
+                /* W4A16: the dequantised weight IS an fp16 number, w = fp16((nibble - 8) * scale[n, k / group]) (the product is
+                 * exact in fp32, so this is one rounding) -- what a W4A16 kernel feeds its fp16 matrix unit; then an fp32 dot */
                 const uint8_t* w = l->w4 + (size_t)n * K / 2;
+                const int G = K / l->group;
                 for (int k = 0; k < K; k += 2) {
-                    wrow[k] = (float)((int)(w[k / 2] & 15) - 8);
-                    wrow[k + 1] = (float)((int)(w[k / 2] >> 4) - 8);
+                    const float sc = h2f(l->scale[(size_t)n * G + k / l->group]);
+                    wrow[k] = rh((float)((int)(w[k / 2] & 15) - 8) * sc);
+                    wrow[k + 1] = rh((float)((int)(w[k / 2] >> 4) - 8) * sc);
                 }
             }
             for (int64_t m = 0; m < M; ++m) {
                 const float* xr = x + m * K;
                 float acc;
-                if (l->qbit == 4) {
-                    acc = 0;
-                    const int G = K / l->group;
-                    for (int g = 0; g < G; ++g)
-                        acc += h2f(l->scale[(size_t)n * G + g]) * dot_f32(xr + g * l->group, wrow + g * l->group, l->group);
-                } else {
-                    acc = dot_f32(xr, wrow, K);
-                    if (l->qbit == 8) acc *= h2f(l->scale[n]);
-                }
+                acc = dot_f32(xr, wrow, K);
+                if (l->qbit == 8) acc *= h2f(l->scale[n]);
                 y[m * N + n] = out_fp32 ? acc : rh(acc);
             }
         }

@@ -250,3 +250,23 @@ def test_llama70b_tp8_rank_slices_w4a16_decode_at_kv2048():
     prompts = [rng.randint(3, 32000, size=40), rng.randint(3, 32000, size=17)]
     check("llama70b_tp8_w4a16_cache_prefill", generate(g, prompts, 2, start=[512, 33]), k=8)
     g.close()
+
+
+def test_one_process_per_rank_over_ipc_handles():
+    """the driver's multi-GPU launch mode (one process per rank, exchange regions shared through hipIpc handles gathered
+    by the launcher, collective self-test, direct collectives) with both processes on device 0: bench.py --gpus 2 self-
+    launches, runs a 2-layer 7B-shaped tensor-parallel decode and must report the direct collectives in use."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PPLHIP_COMM="p2p", PPLHIP_BENCH_ONE_DEVICE="1", OMP_NUM_THREADS="1", PPLHIP_P2P_TIMEOUT_MS="30000")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--layers", "2",
+                          "--batch", "64", "--kv-len", "64", "--no-cpu-baseline", "--prefill-sample", "0"], env=env, timeout=900,
+                         capture_output=True)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    line = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(line) == 1, out.stdout.decode()[-2000:]
+    res = json.loads(line[0])
+    assert res["n_gpus"] == 2 and res["value"] > 0 and res["config"]["collectives"].startswith("direct")

@@ -145,3 +145,16 @@ def test_bench_control_plane_world_size_2_dry_run():
     res = json.loads(line[0])
     assert res["n_gpus"] == 2 and res["steps"] == 3 and res["warmup"] == 1 and res["scaling"] == "strong"
     assert res["dry_run"] is True and res["unique_id_agreed"] is True and res["config"]["parallelism"] == "tp2"
+
+
+def test_bench_self_launches_without_a_launcher():
+    """the driver's N = 1 verb with --gpus 2 and NO torch.distributed.run around it: bench.py re-executes itself under the
+    launcher (one process per GPU) and rank 0 still prints exactly one JSON line on stdout."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                                   "--dry-run"], env=env, timeout=600, stderr=subprocess.DEVNULL).decode()
+    line = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    res = json.loads(line[0])
+    assert res["n_gpus"] == 2 and res["dry_run"] is True and res["unique_id_agreed"] is True
