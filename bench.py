@@ -50,12 +50,11 @@ def attn_bytes_per_launch(B, kv_lens_sum, H, Hkv, D, kv_quant):
     return kv_lens_sum * per_tok + B * H * D * 2 * 2
 
 
-def cpu_baseline(model_kw, kv_len, budget_s=25.0):
-    """the oracle (CPU restatement, 'port') on a bounded sample: decode steps of a batch of 8 at the same kv_len."""
+def cpu_decode_sample(model_kw, kv_len, B, wq, kvq, max_steps, budget_s):
+    """decode steps of the oracle (oracle/llama_ref.c, OpenMP) on the host cores: (tokens/s, steps, setup seconds, threads)"""
     from oracle import ref  # sets OMP_NUM_THREADS to the CPUs this container may really use (cgroup quota)
-    B = 8
-    desc = ref.make_desc(max_position=2048, cache_quant_bit=8, cache_quant_group=8, cache_layout=3, cache_mode=0,
-                         weight_quant_bit=8, **model_kw)
+    desc = ref.make_desc(max_position=2048, cache_quant_bit=kvq, cache_quant_group=8 if kvq else 1, cache_layout=3, cache_mode=0,
+                         weight_quant_bit=wq, **model_kw)
     t0 = time.time()
     m = ref.RefModel(desc)
     m.init_synthetic(1234)
@@ -63,13 +62,16 @@ def cpu_baseline(model_kw, kv_len, budget_s=25.0):
     m.kv_alloc(tokens)
     kc, ks = m.kv_array(0), m.kv_array(1)
     rng = np.random.RandomState(0)
-    kc[:] = rng.randint(-127, 128, size=kc.size, dtype=np.int8)
-    ks[:] = (0.01 + 0.02 * rng.rand(ks.size)).astype(np.float16)
+    if kvq:
+        kc[:] = rng.randint(-127, 128, size=kc.size, dtype=np.int8)
+        ks[:] = (0.01 + 0.02 * rng.rand(ks.size)).astype(np.float16)
+    else:
+        kc[:] = (rng.standard_normal(kc.size).astype(np.float32) * 0.5).astype(np.float16)
     setup_s = time.time() - t0
     cache_idx = (np.arange(B) * (kv_len + 8)).astype(np.int64)
     tok = rng.randint(3, desc.vocab_size, size=B).astype(np.int64)
     steps, t_total = 0, 0.0
-    while steps < 4 and (steps == 0 or t_total + t_total / steps < budget_s):
+    while steps < max_steps and (steps == 0 or t_total + t_total / steps < budget_s):
         st = ref.make_step(tok, np.arange(B + 1), np.full(B, kv_len + steps), cache_idx, B)
         t1 = time.time()
         logits = ref.forward([m], st)
@@ -78,9 +80,65 @@ def cpu_baseline(model_kw, kv_len, budget_s=25.0):
         steps += 1
     cores = ref.lib().ref_num_threads()
     m.close()
-    return {"value": round(B * steps / t_total, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} decode steps of batch {B} at kv_len {kv_len}, same 7B W8A16/int8-KV config "
-                      f"(oracle/llama_ref.c, OpenMP; setup {setup_s:.1f}s not timed)"}
+    return B * steps / t_total, steps, setup_s, cores
+
+
+def cpu_baseline(model_kw, kv_len):
+    """The reference has no CPU path; the baseline is this build's CPU restatement ("port"), timed on the
+    host cores on a bounded sample.  value = BASELINE config 1 as SURVEY.md D5 states it (7B fp16 weights, fp16 KV, batch 1,
+    greedy decode); the W8A16 / int8-KV batch-8 figure of the benchmark configuration is reported beside it."""
+    v1, s1, set1, cores = cpu_decode_sample(model_kw, kv_len, B=1, wq=0, kvq=0, max_steps=8, budget_s=12.0)
+    v8, s8, set8, _ = cpu_decode_sample(model_kw, kv_len, B=8, wq=8, kvq=8, max_steps=4, budget_s=10.0)
+    return {"value": round(v1, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"BASELINE config 1: {s1} greedy decode steps of batch 1 at kv_len {kv_len}, LLaMA-2-7B fp16 weights / fp16 KV "
+                      f"(oracle/llama_ref.c, OpenMP; setup {set1:.1f}s not timed)",
+            "batch8_w8a16_int8kv": {"value": round(v8, 3), "unit": "tokens/s",
+                                    "sample": f"{s8} decode steps of batch 8 at kv_len {kv_len}, W8A16 / int8-g8 KV (setup {set8:.1f}s not timed)"}}
+
+
+def ragged_kv_lengths(B, seed=1234, cap=1024):
+    """running-batch context lengths of a samples_1024.json-shaped load in steady state (prompt log-normal
+    median 30 / mean 104, answer median 286 / mean 315, both clipped to [4, 1024], prompt + answer <= cap): every request
+    is somewhere between its first and its last generated token."""
+    rng = np.random.RandomState(seed)
+    p = np.clip(rng.lognormal(np.log(30.0), 1.577, size=B), 4, 1024).astype(np.int64)
+    o = np.clip(rng.lognormal(np.log(286.0), 0.44, size=B), 4, 1024).astype(np.int64)
+    p = np.minimum(p, cap - 4)
+    o = np.minimum(o, cap - p)
+    return p + (rng.rand(B) * o).astype(np.int64)
+
+
+def serving_leg(model_kw, args):
+    """BASELINE's metric is decode tokens/s + p50 TTFT: the samples_1024-shaped token-in/out load through the C++ generator
+    + engine + hip backend (tools/offline_inference --workload samples1024, the in-process counterpart of the reference's
+    client_qps_measure run): all 1024 requests submitted at once, TTFT = first response - submit per request
+    (tools/client_qps_measure.cc:285-287), p50 / p90 over requests (:337-340), tokens out per second (:331)."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "ppl.llm.serving_amd", "build", "offline_inference")
+    if not os.path.exists(exe):
+        return {"error": "build/offline_inference missing (run __graft_entry__.build())"}
+    with tempfile.TemporaryDirectory() as td:
+        params = dict(num_heads=model_kw["num_heads"], num_kv_heads=model_kw["num_kv_heads"], num_layers=model_kw["num_layers"],
+                      hidden_dim=model_kw["hidden_dim"], intermediate_dim=model_kw["intermediate_dim"], vocab_size=model_kw["vocab_size"],
+                      cache_quant_bit=args.kv_quant, cache_quant_group=8 if args.kv_quant else 1, cache_layout=3, cache_mode=0,
+                      dynamic_batching=True, auto_causal=True, weight_quant_bit=args.weight_quant, weight_quant_group=128,
+                      max_position=2048)
+        path = os.path.join(td, "params.json")
+        json.dump(params, open(path, "w"))
+        cmd = [exe, "--model-param-path", path, "--synthetic-weights", "--workload", "samples1024", "--num-requests", "1024",
+               "--max-seq-len", "1024", "--max-running-batch", str(args.batch), "--max-tokens-per-step", "8192"]
+        t0 = time.time()
+        out = subprocess.run(cmd, capture_output=True, timeout=900)
+        wall = time.time() - t0
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    if out.returncode != 0 or not lines:
+        return {"error": f"offline_inference rc {out.returncode}: {out.stderr.decode()[-300:]}"}
+    r = json.loads(lines[-1])
+    return {"workload": r["workload"] + ", submitted at once, max-running-batch %d" % args.batch, "requests": r["requests"], "failed": r["failed"],
+            "tokens_out_per_s": r["tokens_out_per_s"], "ttft_p50_ms": r["ttft_ms"]["p50"], "ttft_p90_ms": r["ttft_ms"]["p90"],
+            "ttft_p99_ms": r["ttft_ms"]["p99"], "decode_ms_per_token_p50": r["decode_ms_per_token"]["p50"], "steps": r["steps"],
+            "max_running": r["max_running"], "process_wall_s": round(wall, 1)}
 
 
 def dry_run(args, P, dist, rank, world):
@@ -167,6 +225,8 @@ def main():
     ap.add_argument("--kv-quant", type=int, default=8)
     ap.add_argument("--layers", type=int, default=0, help="debug only: override the layer count (result is then INVALID)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-serving-leg", action="store_true", help="skip the samples_1024-shaped serving run (TTFT)")
+    ap.add_argument("--ragged-steps", type=int, default=4, help="decode steps at a samples_1024-shaped ragged kv_len batch (0: skip)")
     ap.add_argument("--tpb", type=int, default=0)
     ap.add_argument("--prefill-sample", type=int, default=1, help="also time one 8192-token prefill step (TTFT proxy)")
     ap.add_argument("--cache-mode", type=int, default=0, choices=[0, 1],
@@ -235,6 +295,9 @@ def main():
     comm_mode = {0: "none", 1: "rccl", 2: "direct xGMI kernels (two-shot, all links)"}[ctx.comm_mode()]
     ctx.init_synthetic(0, 1234)
     kv_tokens = B * total_len if args.cache_mode == 0 else B * ((total_len + 15) // 16) * 16
+    rag_kv = ragged_kv_lengths(B) if (args.ragged_steps > 0 and args.cache_mode == 0) else None
+    if rag_kv is not None:  # the ragged leg re-plans the same slab: request b owns kv_b + steps + 1 contiguous slots
+        kv_tokens = max(kv_tokens, int((rag_kv + args.ragged_steps + 1).sum()))
     cap = ctx.kv_capacity(0.94)
     if kv_tokens > cap:
         sys.exit(f"KV slab needs {kv_tokens} tokens but only {cap} fit")
@@ -287,16 +350,51 @@ def main():
     kv_sum = sum(B * (args.kv_len + i + 1) for i in range(W, W + K))  # keys read per layer over the timed steps
     bytes_total = attn_bytes_per_launch(B * K, kv_sum, H, Hkv, D, args.kv_quant) * desc.num_layers
     achieved = bytes_total / (ms_attn * 1e-3) / 1e9 if ms_attn > 0 else 0.0
-    traffic = None
+    # HBM bytes per launch from the PMC counters: collected OFFLINE by profiles/collect_r02.sh on this very command line
+    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes) and stored with the kv range and the kernel revision it
+    # was taken at; reported only when it matches what this run launched
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "attn_decode_traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and tp == 1:
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            same = (tj.get("batch") == B and tj.get("kv_len_first") == args.kv_len + W + 1 and tj.get("kv_len_last") == args.kv_len + W + K
+                    and tj.get("kv_quant") == args.kv_quant and tj.get("cache_mode") == args.cache_mode)
+            traffic = tj.get("hbm_bytes_per_launch") if same else None
+            traffic_source = tj.get("source_short", "profiles/attn_decode_traffic.json") + ("" if same else " -- NOT for this launch shape, omitted")
         except Exception:
             traffic = None
 
-    if tp > 1:
-        traffic = None  # the PMC figure was collected for the single-GPU launch shape only
+    # ragged leg: the same batch size at a samples_1024-shaped spread of context lengths (4 .. 1024 in ONE step)
+    ragged = None
+    if rag_kv is not None:
+        r_idx = np.concatenate([[0], np.cumsum(rag_kv + args.ragged_steps + 1)[:-1]]).astype(np.int64)
+        tok_r = rng.randint(3, desc.vocab_size, size=B).astype(np.int64)
+
+        def rstep(i, tok_r):
+            st = P.make_step(tok_r, seq_starts, rag_kv - 1 + i, r_idx, B, req_list_changed=1 if i == 0 else 0)
+            ctx.set_inputs(0, st)
+            ctx.run(0)
+            out, _ = ctx.sample(B, top_k=1, req_list_changed=(i == 0))
+            return out.astype(np.int64)
+
+        tok_r = rstep(0, tok_r)   # untimed
+        barrier()
+        ctx.profile_reset(0)
+        t1 = time.perf_counter()
+        for i in range(1, args.ragged_steps + 1):
+            tok_r = rstep(i, tok_r)
+        barrier()
+        dt_r = time.perf_counter() - t1
+        n_r, ms_r = ctx.profile_get(P.PROF_ATTN_DECODE)
+        kv_sum_r = sum(int((rag_kv + i).sum()) for i in range(1, args.ragged_steps + 1))
+        bytes_r = attn_bytes_per_launch(B * args.ragged_steps, kv_sum_r, H, Hkv, D, args.kv_quant) * desc.num_layers
+        ragged = {"kv_len": {"min": int(rag_kv.min()), "p50": int(np.median(rag_kv)), "mean": round(float(rag_kv.mean()), 1), "max": int(rag_kv.max())},
+                  "steps": args.ragged_steps, "ms_per_step": round(dt_r / args.ragged_steps * 1e3, 3),
+                  "tokens_per_s": round(B * args.ragged_steps / dt_r, 1),
+                  "attn_decode_GBps": round(bytes_r / (ms_r * 1e-3) / 1e9, 1) if ms_r > 0 else None,
+                  "attn_decode_frac_of_8TBps": round(bytes_r / (ms_r * 1e-3) / 8e12, 4) if ms_r > 0 else None,
+                  "attn_avg_launch_ms": round(ms_r / max(n_r, 1), 4), "algorithmic_bytes_per_launch": int(bytes_r / max(n_r, 1))}
     extra = {}
     if args.prefill_sample:
         # TTFT proxy: one admission step of 16 x 512-token prompts (max_tokens_per_step 8192), cold cache slots
@@ -333,17 +431,27 @@ def main():
                        "parallelism": f"tp{world}", "layers": desc.num_layers, "collectives": comm_mode},
             "roofline": {"kernel": "attn_decode_kernel<8,128>" if args.kv_quant else "attn_decode_kernel<0,128>",
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                         "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "launches": n_attn, "avg_launch_ms": round(ms_attn / max(n_attn, 1), 4),
                          "algorithmic_bytes_per_launch": int(bytes_total / max(n_attn, 1))},
             "breakdown_ms_per_step": {"attn_decode": round(ms_attn / K, 3), "gemm": round(ms_gemm / K, 3),
                                       "run_total_gpu": round(ms_run / K, 3)},
         }
         res.update(extra)
+        if ragged is not None:
+            res["ragged_batch"] = ragged
         if args.layers:
             res["INVALID"] = "layer count overridden for debugging"
         if args.emulate_tp > 1:
             res["INVALID"] = f"one rank's slice of a tp{args.emulate_tp} step without its peers (profiling only)"
+        ctx.close()   # the serving leg sizes its own KV slab from the free memory
+        if world == 1 and not args.no_serving_leg and not args.layers and not args.emulate_tp:
+            try:
+                sv = serving_leg(mk, args)
+            except Exception as e:
+                sv = {"error": repr(e)}
+            res["serving"] = sv
+            res["ttft_p50_ms"] = sv.get("ttft_p50_ms")
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(mk, args.kv_len)

@@ -1,8 +1,16 @@
 """End-to-end parity of the decoder forward (pplhip_set_inputs / pplhip_run / pplhip_sample) against the CPU oracle
 and the HF golden vectors: packed ragged prefill, decode steps, all cache layouts/modes, fp16 and int8 KV,
-fp16 / W8A16 / W4A16 weights.  Tolerance on logits: |d| <= 1e-3 * max(1, |logit|max) * k with k stated per
-test (north star: "logits within 1e-3 fp16"; the tiny models' logits are O(1)); greedy tokens exact wherever
-the oracle's top-2 margin exceeds the tolerance."""
+fp16 / W8A16 / W4A16 weights.  Tolerance on logits: |d| <= 1e-3 * k * max(1, |logit|max) (north star: "logits within
+1e-3 fp16", i.e. k = 1); greedy tokens exact wherever the oracle's top-2 margin exceeds the tolerance.
+
+k is set per test from the errors the hardware actually produced (profiles/r02_parity_errors.jsonl; every comparison
+appends to that log through tests/parity.py), with ~1.5x headroom.  k = 1 holds for multi-head models with fp16 or
+W8A16 / W4A16 weights.  Documented causes of k > 1:
+  * int8-g8 KV (k 2): quantisation is discontinuous -- K/V inputs that differ from the oracle's by one fp16 rounding can
+    flip a cache byte by one LSB (test_hf_fixture_model checks <= 3 LSB on < 5 % of the bytes), and one flipped byte moves
+    a logit of these tiny models by ~1e-3 of the logit scale;
+  * grouped-query models (k 3; with int8 KV k 6): decode and prefill attention run on the MFMA, which takes the
+    probabilities and the dequantised K/V as fp16 (DESIGN.md numerics) where the oracle keeps fp32."""
 import os
 import tempfile
 
@@ -96,7 +104,8 @@ def test_hf_fixture_model(golden_dir, name, layout, mode, quant):
     ctx.kv_alloc(0, max_tokens)
     steps = hf_logits.shape[1]
     res = generate_both(m, ctx, [rm], desc, prompts, steps, max_tokens)
-    check_steps(res, k=8 if quant else 4)  # int8 KV: a flipped rounding of one cache byte moves a logit by ~1e-2
+    # observed (r02): mha 0.8e-3 / 1.2e-3 (fp16 / int8 KV), gqa 2.1e-3 / 4.2e-3
+    check_steps(res, k={("mha", 0): 1.5, ("mha", 8): 2, ("gqa", 0): 3, ("gqa", 8): 6}[(name, quant)])
     if quant == 0:
         # and against the independent HF vectors (fp32 model vs fp16 activations)
         got = np.stack([r[0] for r in res], 1)
@@ -133,7 +142,7 @@ def test_synthetic_model(wq, kvq, mode, inter):
     rng = np.random.RandomState(7)
     prompts = [rng.randint(3, 1024, size=n) for n in (70, 3, 129, 1, 16)]
     res = generate_both(m, ctx, [rm], desc, prompts, 4, 1024)
-    check_steps(res, k=8 if wq == 4 else 4)
+    check_steps(res, k=1)   # observed (r02): <= 3.5e-4 for every weight / KV format
     ctx.close()
 
 
@@ -153,7 +162,7 @@ def test_uploaded_weights_with_padded_w2_rows():
     ctx.kv_alloc(0, 512)
     rng = np.random.RandomState(3)
     prompts = [rng.randint(3, 512, size=n) for n in (33, 2, 65)]
-    check_steps(generate_both(m, ctx, [rm], desc, prompts, 3, 512), k=8)
+    check_steps(generate_both(m, ctx, [rm], desc, prompts, 3, 512), k=1)   # observed 2.6e-4
     ctx.close()
 
 
@@ -193,9 +202,9 @@ def test_comm_path_and_chunked_overlap_single_gpu(monkeypatch, init):
     chunked = run({"PPLHIP_FORCE_COMM": "1", "PPLHIP_TP_OVERLAP": "1", "PPLHIP_TP_OVERLAP_MIN_TOKENS": "2"})
     for a, b in zip(plain, same_stream):
         assert (a[0] == b[0]).all() and (a[2] == b[2]).all()
-    check_steps(chunked, k=8)
+    check_steps(chunked, k=1)   # observed 5.4e-4
     for a, b in zip(plain, chunked):
-        assert np.abs(a[0] - b[0]).max() <= 4e-3 * max(1.0, np.abs(a[0]).max())
+        assert np.abs(a[0] - b[0]).max() <= 1e-3 * max(1.0, np.abs(a[0]).max())
 
 
 def test_container_load_and_errors(golden_dir):
@@ -319,5 +328,6 @@ def test_exported_hf_checkpoint_runs_on_the_device(tmp_path_factory):
     ctx.set_inputs(0, m.make_step(np.array(prompt), [0, len(prompt)], [0], [0], 0))
     ctx.run(0)
     got = ctx.copy_logits(1)[0]
-    assert np.abs(got - want).max() <= 8e-3 * max(1.0, np.abs(want).max())
+    record_err("exported_hf_checkpoint", np.abs(got - want).max() / max(1.0, np.abs(want).max()), 2e-3)
+    assert np.abs(got - want).max() <= 2e-3 * max(1.0, np.abs(want).max())
     ctx.close()

@@ -300,7 +300,9 @@ def test_attention_prefill_and_mixed(quant, layout, mode, H, Hkv, D):
                                    case.T, 2, case.max_seq_len, case.max_kv_len, H, 1, None, 0, out.data_ptr()))
     # prefill path: K/V dequantised to fp16 and P rounded to fp16 before the MFMAs: 4e-3 relative to |V|max
     vmax = 3.0 if not quant else 0.03 * 127
-    close_f16(out.cpu().numpy(), want, rel=4e-3, abs_=4e-3 * vmax)
+    from tests.parity import record_err
+    record_err(f"attn_mixed_q{quant}_l{layout}m{mode}_{H}_{Hkv}_{D}", float(np.abs(out.cpu().numpy().astype(np.float32) - want).max()) / vmax, 2e-3)
+    close_f16(out.cpu().numpy(), want, rel=2e-3, abs_=2e-3 * vmax)
 
 
 LONG_CASES = [  # (new tokens, cached tokens) per request, (H, Hkv)
@@ -339,8 +341,8 @@ def test_attention_long_prefill_and_cache_prefill(quant, seqlens, start, heads):
     got = out.cpu().numpy().astype(np.float32)
     vmax = 3.0 if not quant else 0.03 * 127
     from tests.parity import record_err
-    record_err(f"attn_long_q{quant}_{seqlens}_{start}_{heads}", float(np.abs(got - want).max()) / vmax, 4e-3)
-    close_f16(got, want, rel=4e-3, abs_=4e-3 * vmax)
+    record_err(f"attn_long_q{quant}_{seqlens}_{start}_{heads}", float(np.abs(got - want).max()) / vmax, 1e-3)
+    close_f16(got, want, rel=1e-3, abs_=1e-3 * vmax)   # observed (r02) <= 5.1e-4 |V|max
 
 
 def test_sampler_greedy_and_topk():

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from tests.conftest import load_pplhip
+from tests.parity import record_err
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -103,6 +104,7 @@ def test_permutation_determinism_and_prefill_decode_consistency(prompts):
     full = ctx.copy_logits(1)[0]
     step = a1[2]
     scale = max(1.0, np.abs(full).max())
+    record_err("7b_prefill_vs_decode_consistency", np.abs(full - step).max() / scale, 1.5e-2)
     assert np.abs(full - step).max() <= 1.5e-2 * scale
     srt = np.sort(full)
     if srt[-1] - srt[-2] > 3e-2 * scale:
@@ -125,6 +127,7 @@ def test_prefix_hit_equals_cold_prefill_full_size():
     ctx.run(0, cache_prefill=1)
     hit = ctx.copy_logits(1)[0]
     scale = max(1.0, np.abs(cold).max())
+    record_err("7b_prefix_hit_vs_cold", np.abs(cold - hit).max() / scale, 1.5e-2)
     assert np.abs(cold - hit).max() <= 1.5e-2 * scale
     ctx.close()
 
@@ -179,6 +182,7 @@ def test_grouped_query_w4_model_invariances(prompts):
             ctx.run(0)
             full = ctx.copy_logits(1)[0]
             scale = max(1.0, np.abs(full).max())
+            record_err("gqa_w4_prefill_vs_decode_consistency", np.abs(full - l1[2]).max() / scale, 1.5e-2)
             assert np.abs(full - l1[2]).max() <= 1.5e-2 * scale
         ctx.close()
         assert np.isfinite(l0).all() and np.isfinite(l1).all()

@@ -151,7 +151,7 @@ def test_tensor_parallel_group_on_one_device(monkeypatch, tp, mode, overlap):
     g.synthetic(31 + tp)
     rng = np.random.RandomState(tp)
     prompts = [rng.randint(3, 2048, size=n) for n in (40, 3, 129, 1, 16, 77)]
-    check(f"tp{tp}_tiny_mode{mode}_ov{int(overlap)}", generate(g, prompts, 4), k=8)
+    check(f"tp{tp}_tiny_mode{mode}_ov{int(overlap)}", generate(g, prompts, 4), k=1.5)   # observed (r02) <= 0.98e-3, int8 KV
     g.close()
 
 
@@ -216,7 +216,7 @@ def test_llama13b_tp2_rank_slices_w8a16():
         g.set_tensors(r, tensors)
     del weights
     prompts = [rng.randint(3, V, size=n) for n in (70, 3, 129, 1, 16)]
-    check("llama13b_tp2_w8a16_int8kv", generate(g, prompts, 3), k=8)
+    check("llama13b_tp2_w8a16_int8kv", generate(g, prompts, 3), k=4)   # observed 2.5e-3 (int8 KV, 40 heads, K up to 6912)
     g.close()
 
 
@@ -245,10 +245,10 @@ def test_llama70b_tp8_rank_slices_w4a16_decode_at_kv2048():
         res.append((got, want, gtok))
         tok = want.argmax(-1).astype(np.int64)
         start = start + 1
-    check("llama70b_tp8_w4a16_decode_kv2048", res, k=8)
+    check("llama70b_tp8_w4a16_decode_kv2048", res, k=6)   # observed 4.1e-3: grouped-query MFMA decode over int8 KV (see test_gpu_model.py)
     # cache-prefill: 40 and 17 new tokens on top of 512 and 33 cached ones (history from the synthetic slab)
     prompts = [rng.randint(3, 32000, size=40), rng.randint(3, 32000, size=17)]
-    check("llama70b_tp8_w4a16_cache_prefill", generate(g, prompts, 2, start=[512, 33]), k=8)
+    check("llama70b_tp8_w4a16_cache_prefill", generate(g, prompts, 2, start=[512, 33]), k=1.5)   # observed 5.4e-4
     g.close()
 
 
