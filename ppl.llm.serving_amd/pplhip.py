@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_DIR, "csrc", "libpplhip.so")
+LIB_PATH = os.environ.get("PPLHIP_LIB") or os.path.join(_DIR, "csrc", "libpplhip.so")   # PPLHIP_LIB: diagnosis builds (profiles/)
 UNIQUE_ID_BYTES = 128
 IPC_HANDLE_BYTES = 64
 COMM_NONE, COMM_RCCL, COMM_P2P = 0, 1, 2
