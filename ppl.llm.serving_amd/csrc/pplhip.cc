@@ -502,6 +502,16 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
     pplhip_ctx* cp = c.get();
     std::vector<int> devs(n);
     for (int r = 0; r < n; ++r) devs[r] = opts->device_ids ? opts->device_ids[r] : r;
+    if (!opts->device_ids) {  // PPLHIP_DEVICE_IDS=0,0,...: device of each local rank (tests: a whole group on one GPU)
+        if (const char* e = getenv("PPLHIP_DEVICE_IDS")) {
+            int r = 0;
+            for (const char* q = e; *q && r < n; ++r) {
+                devs[r] = atoi(q);
+                while (*q && *q != ',') ++q;
+                if (*q == ',') ++q;
+            }
+        }
+    }
 
     // communicators (replaces ppl::common::InitNccl, resource_manager.cc:393)
     // PPLHIP_FORCE_COMM=1: create the communicator and run every collective even at world size 1 (an identity) --

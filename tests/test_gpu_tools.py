@@ -84,3 +84,25 @@ def test_offline_inference_samples_workload_and_prefix_benchmark():
     res = json.loads(out.strip().splitlines()[-1])
     assert res["first_ttft_ms"] > 0 and res["prefix_ttft_ms"] > 0
     assert "first ttft:" in out and "prefix ttft:" in out
+
+
+def test_reference_engine_and_generator_drive_the_hip_backend_unmodified():
+    """SURVEY.md 8(b) B1/B2 on the device: build/ref_backend_driver is the REFERENCE'S OWN llm_generator.cc + llm_engine.cc
+    (compiled in place from /root/reference/src by `make ref` in the build container, no line changed) over
+    src/backends/hip_nn -- ppl::nn::Runtime / Tensor / Engine objects on top of libpplhip.  Same synthetic model, same four
+    prompts as offline_inference --workload prompts4 (the repo's generator + engine): the generated tokens must be identical,
+    at tensor-parallel size 1 and 2 (both ranks on device 0)."""
+    drv = os.path.join(PKG, "build", "ref_backend_driver")
+    if not os.path.exists(drv):
+        pytest.skip("build/ref_backend_driver is built only where the reference tree exists (make ref)")
+
+    def answers(out):
+        return [[int(x) for x in l.split(":")[1].split()] for l in out.splitlines() if l.startswith("Answer tokens:")]
+
+    for tp in (1, 2):
+        env = dict(os.environ, GPU_MAX_HW_QUEUES="24", PPLHIP_DEVICE_IDS=",".join(["0"] * tp))
+        mine = subprocess.check_output([tool("offline_inference"), "--model-param-path", CFG, "--synthetic-weights", "--kv-cache-max-tokens",
+                                        "8192", "--workload", "prompts4", "--tensor-parallel-size", str(tp)], timeout=300, env=env).decode()
+        theirs = subprocess.check_output([drv, CFG, str(tp)], timeout=300, env=env).decode()
+        a, b = answers(mine), answers(theirs)
+        assert [len(x) for x in a] == [8, 9, 10, 11] and a == b, (tp, a, b)

@@ -1,7 +1,10 @@
 """Host logic of the hot path (hashing, prefix cache, allocators, request scheduler, ModelInput packing):
   1. the Python oracle (oracle/host_logic.py) against golden values captured from the reference's own code;
   2. the C++ implementation (ppl.llm.serving_amd/src, driven by tests/host/sched_trace with a fake backend)
-     against the golden values and, step by step and bit-exactly, against the oracle on scripted request traces."""
+     against the golden values and, step by step and bit-exactly, against the oracle on scripted request traces;
+  3. where /root/reference exists (the build container): THE REFERENCE'S OWN llm_generator.cc / llm_engine.cc, compiled in place
+     against the ppl.nn / ppl.common surface of src/compat (tests/host/ref_sched_trace.cc, `make ref`), on the same traces --
+     what its engine binds by index and copies per step equals what the repo's generator packs."""
 import json
 import os
 import subprocess
@@ -222,3 +225,107 @@ def test_cpp_cancel_on_a_quiet_step_marks_the_batch_changed(trace_bin):
     sc2.pop("cancel")
     _, responses2, _ = compare(trace_bin, sc2)
     assert responses[1] == responses2[1] and responses[2] == responses2[2]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 3. the reference's own generator + engine, compiled in place (boundary proof)
+# ---------------------------------------------------------------------------------------------------------------
+REFERENCE = "/root/reference"
+REF_TRACE = os.path.join(PKG, "build", "ref_sched_trace")
+
+
+@pytest.fixture(scope="module")
+def ref_trace_bin():
+    if not os.path.isdir(os.path.join(REFERENCE, "src", "generator")):
+        pytest.skip("the reference tree is not on this machine (GPU box): nothing to compile")
+    subprocess.check_call(["make", "-s", "-C", PKG, "ref"])
+    return REF_TRACE
+
+
+def compare_with_reference(ref_trace_bin, sc, skip_upload_flag_at=()):
+    """the reference-compiled generator on scenario `sc` against the oracle (== the repo's generator, tests above)"""
+    steps, responses, failed = hl.simulate(sc)
+    sc = dict(sc, expect_done=sum(1 for r in responses.values() if r["finish"]) + len(failed))
+    rsteps, rfinal = run_cpp(ref_trace_bin, sc)
+    assert len(rsteps) == len(steps), (len(rsteps), len(steps))
+    mode = sc["model"].get("cache_mode", 0)
+    for a, b in zip(rsteps, steps):
+        for k in ("step", "decoding_batches", "max_seq_len", "max_kv_len", "token_inputs", "seq_starts", "kv_starts", "start_pos", "prefix_hit"):
+            assert a[k] == b[k], (b["step"], k, a[k], b[k])
+        if mode == 0:
+            assert a["cache_indices"] == b["cache_indices"], b["step"]
+        else:
+            assert a["max_pages"] == b["max_pages"] and a["page_list"] == b["page_list"], b["step"]
+            if b["step"] not in skip_upload_flag_at:
+                assert a["pages_uploaded"] == b["req_list_changed"], b["step"]   # llm_engine.cc:67-71
+    assert {int(k): v for k, v in rfinal["responses"].items()} == responses
+    assert sorted(int(k) for k in rfinal["failed"]) == sorted(failed)
+    return rsteps
+
+
+def test_reference_sources_scheduler_example(ref_trace_bin, golden):
+    compare_with_reference(ref_trace_bin, golden["scheduler_example"]["scenario"])
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_reference_sources_contiguous_mode_with_kv_pressure(ref_trace_bin, seed):
+    rng = np.random.RandomState(seed)
+    sc = {"model": {"cache_mode": 0, "vocab_size": 997},
+          "generator": {"max_running_batch": 6, "max_tokens_per_step": 48, "max_prefill_batch": 3, "max_cooldown_request": 2,
+                        "stop_tokens": [5, 6, 7, 8, 9, 10, 11, 12]},
+          "kv_cache_max_tokens": 160, "requests": rand_requests(rng, 30, 997, 20, 12)}
+    for r in sc["requests"][::4]:
+        r["stop_tokens"] = list(range(100, 140))
+    sc["requests"][3]["early_stopping"] = False
+    compare_with_reference(ref_trace_bin, sc)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_reference_sources_paged_mode(ref_trace_bin, seed):
+    rng = np.random.RandomState(100 + seed)
+    sc = {"model": {"cache_mode": 1, "page_size": 4, "vocab_size": 500},
+          "generator": {"max_running_batch": 8, "max_tokens_per_step": 64, "max_prefill_batch": 4, "enable_penalty": True},
+          "kv_cache_max_tokens": 256, "requests": rand_requests(rng, 24, 500, 18, 9)}
+    compare_with_reference(ref_trace_bin, sc)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_reference_sources_prefix_cache(ref_trace_bin, seed):
+    rng = np.random.RandomState(200 + seed)
+    shared = rng.randint(3, 300, size=24).tolist()
+    reqs = rand_requests(rng, 20, 300, 10, 6, shared_prefix=shared)
+    reqs.append({"id": 20, "tokens": shared[:16], "generation_length": 3})
+    reqs.append({"id": 21, "tokens": shared[:16], "generation_length": 2})
+    sc = {"model": {"cache_mode": 1, "page_size": 4, "vocab_size": 300},
+          "generator": {"max_running_batch": 6, "max_tokens_per_step": 128, "enable_prefix_cache": True},
+          "kv_cache_max_tokens": 120, "requests": reqs}
+    steps = compare_with_reference(ref_trace_bin, sc)
+    assert any(s["prefix_hit"] for s in steps)
+
+
+def test_reference_sources_execute_failure(ref_trace_bin):
+    rng = np.random.RandomState(7)
+    sc = {"model": {"cache_mode": 1, "page_size": 8, "vocab_size": 600}, "generator": {"max_running_batch": 8},
+          "kv_cache_max_tokens": 512, "requests": rand_requests(rng, 6, 600, 12, 10), "fail_at_run": 3}
+    for r in sc["requests"]:
+        r["generation_length"] = 8
+    compare_with_reference(ref_trace_bin, sc)
+
+
+def test_reference_sources_cancel_differs_only_in_the_documented_flag(ref_trace_bin):
+    """a cancel on a quiet step: same packing, same tokens -- but the reference does NOT re-upload the page table on the next
+    step (the hole the repo closes on purpose, llm_generator.cc DeleteTasks): that one flag is the whole difference."""
+    sc = {"model": {"cache_mode": 1, "page_size": 4, "vocab_size": 700}, "generator": {"max_running_batch": 8},
+          "kv_cache_max_tokens": 256,
+          "requests": [{"id": i, "tokens": [10 + i, 20 + i, 30 + i, 40 + i, 50 + i], "generation_length": 12, "early_stopping": False}
+                       for i in range(3)],
+          "cancel": [{"at_step": 3, "id": 0}]}
+    steps, responses, failed = hl.simulate(sc)
+    sc2 = dict(sc, expect_done=2)
+    rsteps, rfinal = run_cpp(ref_trace_bin, sc2)
+    assert len(rsteps) == len(steps)
+    for a, b in zip(rsteps, steps):
+        for k in ("decoding_batches", "token_inputs", "seq_starts", "kv_starts", "start_pos"):
+            assert a[k] == b[k], (b["step"], k)
+    assert steps[4]["req_list_changed"] == 1 and rsteps[4]["pages_uploaded"] == 0     # the repo re-uploads, the reference does not
+    assert rsteps[4]["page_list"] != steps[4]["page_list"]                              # ... and so runs rows 1, 2 on row 0's stale table
