@@ -328,6 +328,6 @@ def test_exported_hf_checkpoint_runs_on_the_device(tmp_path_factory):
     ctx.set_inputs(0, m.make_step(np.array(prompt), [0, len(prompt)], [0], [0], 0))
     ctx.run(0)
     got = ctx.copy_logits(1)[0]
-    record_err("exported_hf_checkpoint", np.abs(got - want).max() / max(1.0, np.abs(want).max()), 2e-3)
-    assert np.abs(got - want).max() <= 2e-3 * max(1.0, np.abs(want).max())
+    record_err("exported_hf_checkpoint", np.abs(got - want).max() / max(1.0, np.abs(want).max()), 2.5e-3)   # observed (r02) 1.7e-3, int8 KV
+    assert np.abs(got - want).max() <= 2.5e-3 * max(1.0, np.abs(want).max())
     ctx.close()

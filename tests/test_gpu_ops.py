@@ -301,8 +301,8 @@ def test_attention_prefill_and_mixed(quant, layout, mode, H, Hkv, D):
     # prefill path: K/V dequantised to fp16 and P rounded to fp16 before the MFMAs: 4e-3 relative to |V|max
     vmax = 3.0 if not quant else 0.03 * 127
     from tests.parity import record_err
-    record_err(f"attn_mixed_q{quant}_l{layout}m{mode}_{H}_{Hkv}_{D}", float(np.abs(out.cpu().numpy().astype(np.float32) - want).max()) / vmax, 2e-3)
-    close_f16(out.cpu().numpy(), want, rel=2e-3, abs_=2e-3 * vmax)
+    record_err(f"attn_mixed_q{quant}_l{layout}m{mode}_{H}_{Hkv}_{D}", float(np.abs(out.cpu().numpy().astype(np.float32) - want).max()) / vmax, 1e-3)
+    close_f16(out.cpu().numpy(), want, rel=1e-3, abs_=1e-3 * vmax)   # observed (r02) <= 6.5e-4 |V|max
 
 
 LONG_CASES = [  # (new tokens, cached tokens) per request, (H, Hkv)

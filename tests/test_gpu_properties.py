@@ -104,10 +104,12 @@ def test_permutation_determinism_and_prefill_decode_consistency(prompts):
     full = ctx.copy_logits(1)[0]
     step = a1[2]
     scale = max(1.0, np.abs(full).max())
-    record_err("7b_prefill_vs_decode_consistency", np.abs(full - step).max() / scale, 1.5e-2)
-    assert np.abs(full - step).max() <= 1.5e-2 * scale
+    # two different kernel paths over 32 layers with int8 KV (MFMA prefill attention + tile GEMM vs the VALU decode kernel +
+    # skinny GEMM): observed (r02) 7.0e-3
+    record_err("7b_prefill_vs_decode_consistency", np.abs(full - step).max() / scale, 1e-2)
+    assert np.abs(full - step).max() <= 1e-2 * scale
     srt = np.sort(full)
-    if srt[-1] - srt[-2] > 3e-2 * scale:
+    if srt[-1] - srt[-2] > 2e-2 * scale:
         assert full.argmax() == step.argmax()
     ctx.close()
 
@@ -127,8 +129,8 @@ def test_prefix_hit_equals_cold_prefill_full_size():
     ctx.run(0, cache_prefill=1)
     hit = ctx.copy_logits(1)[0]
     scale = max(1.0, np.abs(cold).max())
-    record_err("7b_prefix_hit_vs_cold", np.abs(cold - hit).max() / scale, 1.5e-2)
-    assert np.abs(cold - hit).max() <= 1.5e-2 * scale
+    record_err("7b_prefix_hit_vs_cold", np.abs(cold - hit).max() / scale, 1e-2)   # observed (r02) 5.8e-3
+    assert np.abs(cold - hit).max() <= 1e-2 * scale
     ctx.close()
 
 
@@ -182,8 +184,8 @@ def test_grouped_query_w4_model_invariances(prompts):
             ctx.run(0)
             full = ctx.copy_logits(1)[0]
             scale = max(1.0, np.abs(full).max())
-            record_err("gqa_w4_prefill_vs_decode_consistency", np.abs(full - l1[2]).max() / scale, 1.5e-2)
-            assert np.abs(full - l1[2]).max() <= 1.5e-2 * scale
+            record_err("gqa_w4_prefill_vs_decode_consistency", np.abs(full - l1[2]).max() / scale, 1e-3)   # observed (r02) 1e-4
+            assert np.abs(full - l1[2]).max() <= 1e-3 * scale
         ctx.close()
         assert np.isfinite(l0).all() and np.isfinite(l1).all()
         if ref_l is None:
