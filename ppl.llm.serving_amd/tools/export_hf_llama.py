@@ -32,9 +32,14 @@ def load_state_dict(model_dir):
     if st:
         from safetensors import safe_open
         for path in st:
-            with safe_open(path, framework="np") as f:
-                for k in f.keys():
-                    sd[k] = f.get_tensor(k)
+            try:
+                with safe_open(path, framework="np") as f:
+                    for k in f.keys():
+                        sd[k] = f.get_tensor(k)
+            except (TypeError, ValueError):   # bf16 checkpoints: numpy has no bfloat16, go through torch
+                with safe_open(path, framework="pt") as f:
+                    for k in f.keys():
+                        sd[k] = f.get_tensor(k).float().numpy()
         return sd
     bins = sorted(glob.glob(os.path.join(model_dir, "pytorch_model*.bin")))
     if not bins:

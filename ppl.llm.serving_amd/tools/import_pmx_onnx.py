@@ -39,7 +39,11 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import export_hf_llama as X  # noqa: E402  (container writer and quantisers)
 
 # TensorProto.DataType (onnx.proto:479-507) -> numpy
-DTYPES = {1: np.float32, 2: np.uint8, 3: np.int8, 6: np.int32, 7: np.int64, 10: np.float16, 11: np.float64}
+DTYPES = {1: np.float32, 2: np.uint8, 3: np.int8, 6: np.int32, 7: np.int64, 10: np.float16, 11: np.float64,
+          16: np.uint16}   # 16 = BFLOAT16: read as raw 16-bit patterns, widened to float32 below
+ONNX_DTYPE_NAMES = {0: "UNDEFINED", 8: "STRING", 9: "BOOL", 12: "UINT32", 13: "UINT64", 14: "COMPLEX64", 15: "COMPLEX128", 17: "FLOAT8E4M3FN",
+                    18: "FLOAT8E4M3FNUZ", 19: "FLOAT8E5M2", 20: "FLOAT8E5M2FNUZ", 21: "UINT4", 22: "INT4"}
+UNSUPPORTED = {}           # initializer name -> ONNX data type it was stored in (skipped; named if somebody needs it later)
 
 
 # ---------------------------------------------------------------------------------------------- protobuf wire format
@@ -128,7 +132,8 @@ def read_initializers(path):
             elif tf in (4, 5, 7) and tw == 2:   # float_data / int32_data / int64_data, packed
                 typed[tf] = tv
         if dtype not in DTYPES:
-            continue                 # strings, bools, bf16 ...: nothing this importer needs
+            UNSUPPORTED[name] = ONNX_DTYPE_NAMES.get(dtype, str(dtype))   # strings, bools, fp8 ...: reported if a weight needs it
+            continue
         np_t = np.dtype(DTYPES[dtype])
         count = int(np.prod(dims)) if dims else 1
         if location == 1 or ext:     # EXTERNAL (onnx.proto:602)
@@ -152,6 +157,8 @@ def read_initializers(path):
             arr = vals.astype(np.uint16).view(np.float16) if dtype == 10 else vals.astype(np_t)
         else:
             arr = np.zeros(count, dtype=np_t)
+        if dtype == 16:             # bfloat16 bit patterns -> float32 (exact)
+            arr = (arr.astype(np.uint32) << 16).view(np.float32)
         out[name] = arr.reshape(dims)
     return out
 
@@ -172,6 +179,8 @@ def convert_slice(sd, p, rank, tp, quant, group, interleaved_rope):
 
     def need(name):
         if name not in sd:
+            if name in UNSUPPORTED:
+                raise TypeError(f"model_slice_{rank}/model.onnx stores '{name}' as ONNX {UNSUPPORTED[name]}, which this importer cannot read")
             raise KeyError(f"model_slice_{rank}/model.onnx has no initializer '{name}'")
         return np.asarray(sd[name], dtype=np.float32)
 

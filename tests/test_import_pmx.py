@@ -49,6 +49,8 @@ def fld(num, wt, payload):
 def tensor_proto(name, arr, form, ext_file=None, ext_off=0):
     """TensorProto (onnx.proto:479-602) in one of the encodings torch / onnx tooling produce"""
     dt = {np.dtype(np.float32): 1, np.dtype(np.float16): 10, np.dtype(np.int64): 7}[arr.dtype]
+    if form.startswith("as_dtype:"):      # raw bytes stored under another ONNX data type (16 = bfloat16, 17 = float8 ...)
+        dt, form = int(form.split(":")[1]), "raw"
     dims = b"".join(fld(1, 0, varint(d)) for d in arr.shape) if form != "packed_dims" else fld(1, 2, b"".join(varint(d) for d in arr.shape))
     body = dims + fld(2, 0, varint(dt)) + fld(8, 2, name.encode())
     if form in ("raw", "packed_dims"):
@@ -208,4 +210,33 @@ def test_errors_name_the_missing_piece(tmp_path):
         imp.convert_dir(str(tmp_path / "pmx"), str(tmp_path / "out"))
     os.rename(tmp_path / "pmx" / "model_slice_0", tmp_path / "pmx" / "model_slice_1")
     with pytest.raises(ValueError, match="model_slice_0"):
+        imp.convert_dir(str(tmp_path / "pmx"), str(tmp_path / "out"))
+
+
+def test_bfloat16_initializers_are_read_and_unsupported_ones_are_named(tmp_path):
+    """a bf16 export loads (bit patterns widened to float32, exact); an initializer in a type the importer cannot read is
+    reported with its name and ONNX type when a weight needs it -- not as a bare "no initializer"."""
+    sd = hf_state_dict(6)
+    t = pmx_slices(sd, 1, True, False)[0]
+    d = tmp_path / "pmx" / "model_slice_0"
+    os.makedirs(d)
+    forms = []
+    bf = {}
+    for name, arr in t.items():
+        if name.endswith("attention.wo.weight"):                        # store as bfloat16 bit patterns
+            hi = (arr.astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+            bf[name] = (hi.astype(np.uint32) << 16).view(np.float32)
+            t[name] = hi.view(np.float16)                               # (tensor_proto keys on the numpy dtype; bytes are what matter)
+            forms.append("as_dtype:16")
+        else:
+            forms.append("raw")
+    write_onnx(str(d / "model.onnx"), t, forms)
+    got = imp.read_initializers(str(d / "model.onnx"))
+    for name, want in bf.items():
+        assert got[name].dtype == np.float32 and (got[name] == want).all()
+    forms[list(t).index("layers.0.attention.wo.weight")] = "as_dtype:17"   # float8: unreadable
+    write_onnx(str(d / "model.onnx"), t, forms)
+    json.dump({"num_heads": 4, "num_kv_heads": 2, "num_layers": 2, "hidden_dim": 256, "intermediate_dim": 512, "vocab_size": 320},
+              open(tmp_path / "pmx" / "params.json", "w"))
+    with pytest.raises(TypeError, match="layers.0.attention.wo.weight.*FLOAT8E4M3FN"):
         imp.convert_dir(str(tmp_path / "pmx"), str(tmp_path / "out"))
