@@ -16,6 +16,7 @@
 #include "../common/request.h"
 #include "../common/resource.h"
 #include "../engine/llm_engine.h"
+#include "../tokenizer/tokenizer.h"
 #include "../utils/index_manager.h"
 #include "../utils/mpsc_request_scheduler.h"
 #include "../utils/prefix_cache_manager.h"
@@ -24,16 +25,6 @@
 #include "ppl/common/threadpool.h"
 
 namespace ppl { namespace llm {
-
-// Optional text path (reference src/tokenizer/tokenizer.h).  The hot path is token-in/token-out
-// (llm_generator.cc:790-801); without a tokenizer, text requests are rejected with RC_UNSUPPORTED.
-class Tokenizer {
-public:
-    virtual ~Tokenizer() {}
-    virtual void Encode(const char* prompt, uint32_t len, std::vector<int>* token_ids) const = 0;
-    virtual void Decode(int* token_ids, uint32_t len, std::string* output) const = 0;
-    virtual int GetEosId() const = 0;
-};
 
 // one generated token on its way to the connection
 struct TidGenToken final {

@@ -31,6 +31,10 @@ struct JsonValue {
         const JsonValue* v = Find(key);
         return v && v->type == NUMBER ? v->num : dflt;
     }
+    std::string GetString(const std::string& key, const std::string& dflt) const {
+        const JsonValue* v = Find(key);
+        return v && v->type == STRING ? v->str : dflt;
+    }
     bool GetBool(const std::string& key, bool dflt) const {
         const JsonValue* v = Find(key);
         if (!v) return dflt;

@@ -1,7 +1,8 @@
 // offline_inference: the in-process driver of the hot path (reference tools/offline_inference.cc:303-417) on the
-// hip backend.  Token-in/token-out (no tokenizer is available offline):
-//   --workload prompts4     the reference's smoke run: 4 fixed prompts, generation_length 8 + i, prints the generated
-//                           token ids per prompt and the generation time (offline_inference.cc:376-413)
+// hip backend.
+//   --workload prompts4     the reference's smoke run: 4 fixed prompts, generation_length 8 + i, prints the answers and the
+//                           generation time (offline_inference.cc:304-309,376-413).  With --tokenizer-path the prompts are the
+//                           reference's TEXTS, tokenised / detokenised by src/tokenizer; without it their token-id stand-ins
 //   --workload samples1024  a samples_1024.json-shaped token-in/out load (the reference's client_qps_measure workload,
 //                           tools/client_qps_measure.cc:54-96): N requests, log-normal prompt / answer lengths, EOS
 //                           ignored; prints ONE JSON line with tokens/s and the TTFT distribution
@@ -12,6 +13,7 @@
 #include <thread>
 
 #include "tool_common.h"
+#include "tokenizer/tokenizer_factory.h"
 
 using namespace ppl::llm;
 using namespace ppl::common;
@@ -38,6 +40,16 @@ int main(int argc, char** argv) {
     }
     Resource resource;
     resource_manager.FillResource(&resource);
+    std::unique_ptr<Tokenizer> tokenizer;
+    if (!a.Str("--tokenizer-path").empty()) {   // offline_inference.cc:351-358
+        tokenizer.reset(TokenizerFactory::Create(a.Str("--model-type"), a.Str("--tokenizer-type"), a.Str("--tokenizer-path"),
+                                                 a.Str("--tokenizer-config-path")));
+        if (!tokenizer) {
+            std::cerr << "create tokenizer failed\n";
+            return -1;
+        }
+        resource.tokenizer = tokenizer.get();
+    }
 
     // ---- the requests ------------------------------------------------------------------------------------
     std::vector<std::shared_ptr<Request>> requests;
@@ -48,10 +60,14 @@ int main(int argc, char** argv) {
         const std::vector<std::vector<int>> prompts = {
             {1, 15043, 29892, 590, 1024, 338}, {1, 450, 6673, 310, 278, 3303, 3900, 338},
             {1, 450, 7483, 310, 3444, 338}, {1, 450, 5434, 310, 319, 29902, 338}};
+        static const char* texts[4] = {"Hello, my name is", "The president of the United States is", "The capital of France is",
+                                       "The future of AI is"};   // offline_inference.cc:304-309
         for (size_t i = 0; i < prompts.size(); ++i) {
-            auto r = std::make_shared<Request>(i, "", 1.0f, 8 + (uint32_t)i);
-            r->token_ids = std::make_shared<std::vector<int>>();
-            for (int t : prompts[i]) r->token_ids->push_back(t % mc.vocab_size);
+            auto r = std::make_shared<Request>(i, tokenizer ? texts[i] : "", 1.0f, 8 + (uint32_t)i);
+            if (!tokenizer) {
+                r->token_ids = std::make_shared<std::vector<int>>();
+                for (int t : prompts[i]) r->token_ids->push_back(t % mc.vocab_size);
+            }
             requests.push_back(r);
         }
     } else if (workload == "samples1024") {
@@ -99,6 +115,7 @@ int main(int argc, char** argv) {
 
     if (workload == "prompts4") {
         for (auto& r : requests) {
+            if (tokenizer) std::cout << "Prompt: " << r->prompt << "\nAnswer: " << conn.records()[r->id].text << "\n";
             std::cout << "Prompt tokens:";
             for (int t : *r->token_ids) std::cout << " " << t;
             std::cout << "\nAnswer tokens:";

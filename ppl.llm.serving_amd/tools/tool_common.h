@@ -42,9 +42,9 @@ inline void DefineCommonFlags(Args* a) {
     a->Def("--disable-graph-fusion", "false", "accepted; ignored", true);
     a->Def("--stop-tokens", "", "stop tokens list");
     a->Def("--special_tokens", "", "special tokens");
-    a->Def("--tokenizer-path", "", "unused: token-in/token-out only");
-    a->Def("--tokenizer-type", "sentencepiece", "unused");
-    a->Def("--tokenizer-config-path", "", "unused");
+    a->Def("--tokenizer-path", "", "tokenizer.model (sentencepiece); empty: token-in/token-out only");
+    a->Def("--tokenizer-type", "sentencepiece", "sentencepiece (the huggingface json tokenizer is not provided)");
+    a->Def("--tokenizer-config-path", "", "unused by the sentencepiece tokenizer");
     a->Def("--enable-prefix-cache", "false", "is enable prefix cache", true);
     a->Def("--max-prefill-batch", "64", "max prefill batches per step");
     a->Def("--enable-profiling", "false", "print profiling message", true);
@@ -110,6 +110,7 @@ class LocalConnection final : public ppl::llm::Connection {
 public:
     struct Rec {
         std::vector<int> tokens;
+        std::string text;
         Clock::time_point submit, first, last;
         bool finished = false, failed = false;
     };
@@ -126,6 +127,7 @@ public:
             Rec& rec = recs_[r.id];
             if (rec.tokens.empty()) rec.first = now;
             rec.tokens.push_back(r.token);
+            rec.text += r.generated;   // text requests: the detokenised piece(s) of this response
             rec.last = now;
             if (r.finish_flag != ppl::llm::FinishFlag::NOT_FINISHED) {
                 rec.finished = true;

@@ -19,6 +19,7 @@
 #include "common/request.h"
 #include "common/resource.h"
 #include "generator/llm_generator.h"
+#include "tokenizer/tokenizer_factory.h"
 #include "utils/index_manager.h"
 #include "utils/mini_json.h"
 #include "utils/mpsc_request_scheduler.h"
@@ -55,7 +56,9 @@ public:
         for (int64_t b = 0; b < B_; ++b) {
             const int64_t last = tok_[seq_[b + 1] - 1];
             const int64_t kv = sp_[b] + (seq_[b + 1] - seq_[b]);
-            const int64_t t = (31 * last + 7 * kv + 3) % vocab_;
+            int64_t t = (31 * last + 7 * kv + 3) % vocab_;
+            auto it = chain_.find(last);            // scripted continuation (detokeniser tests): token -> next token
+            if (it != chain_.end()) t = it->second;
             logits_[(size_t)b * vocab_ + t] = 1.f;
         }
         return RC_SUCCESS;
@@ -65,6 +68,7 @@ public:
         return logits_.data();
     }
     int fail_at_run_ = -1;
+    std::map<int64_t, int64_t> chain_;
 
 private:
     int vocab_;
@@ -102,6 +106,7 @@ public:
         std::lock_guard<std::mutex> g(mu_);
         for (const auto& r : rsps) {
             tokens_[r.id].push_back(r.token);
+            texts_[r.id].push_back(r.generated);
             if (r.finish_flag != FinishFlag::NOT_FINISHED) {
                 finish_[r.id] = (int)r.finish_flag;
                 ++done_;
@@ -123,6 +128,7 @@ public:
     std::condition_variable cv_;
     size_t done_ = 0;
     std::map<uint64_t, std::vector<int>> tokens_;
+    std::map<uint64_t, std::vector<std::string>> texts_;   // Response::generated per response (text requests)
     std::map<uint64_t, int> finish_, failed_;
 };
 
@@ -185,6 +191,14 @@ int RunScenario(const char* path) {
     pool.Init(1);
     FakeRuntime rt(mc.vocab_size);
     rt.fail_at_run_ = (int)doc.GetInt("fail_at_run", -1);
+    if (const utils::JsonValue* ch = doc.Find("chain"))
+        for (const auto& e : ch->arr) rt.chain_[e.GetInt("from", -1)] = e.GetInt("to", 0);
+    std::unique_ptr<Tokenizer> tokenizer;
+    const std::string tok_path = doc.GetString("tokenizer", "");
+    if (!tok_path.empty()) {
+        tokenizer.reset(TokenizerFactory::Create("llama", "sentencepiece", tok_path, ""));
+        if (!tokenizer) { std::cerr << "cannot load tokenizer " << tok_path << "\n"; return 2; }
+    }
     FakePostProcessor pp;
     Resource res;
     res.tensor_parallel_size = 1;
@@ -193,6 +207,7 @@ int RunScenario(const char* path) {
     res.items[0].runtime = &rt;
     res.post_processor = &pp;
     res.device_worker_pool_ = &pool;
+    res.tokenizer = tokenizer.get();
 
     RecordingConnection conn;
     TraceCtx tctx;
@@ -210,8 +225,12 @@ int RunScenario(const char* path) {
             req->id = (uint64_t)r.GetInt("id", 0);
             req->generation_length = (int32_t)r.GetInt("generation_length", 1);
             req->early_stopping = r.GetBool("early_stopping", true);
-            req->token_ids = std::make_shared<std::vector<int>>();
-            for (const auto& t : r.Find("tokens")->arr) req->token_ids->push_back((int)t.AsInt());
+            if (const utils::JsonValue* toks = r.Find("tokens")) {
+                req->token_ids = std::make_shared<std::vector<int>>();
+                for (const auto& t : toks->arr) req->token_ids->push_back((int)t.AsInt());
+            } else {
+                req->prompt = r.GetString("prompt", "");     // text request: tokenised by the generator (Process)
+            }
             if (const utils::JsonValue* st = r.Find("stop_tokens")) {
                 req->stop_tokens = std::make_shared<std::unordered_set<int>>();
                 for (const auto& v : st->arr) req->stop_tokens->insert((int)v.AsInt());
@@ -233,6 +252,18 @@ int RunScenario(const char* path) {
     for (auto& kv : conn.tokens_) {
         ss << (first ? "" : ",") << "\"" << kv.first << "\":{\"tokens\":" << Arr(kv.second) << ",\"finish\":"
            << (conn.finish_.count(kv.first) ? conn.finish_[kv.first] : 0) << "}";
+        first = false;
+    }
+    ss << "},\"texts_hex\":{";
+    first = true;
+    for (auto& kv : conn.texts_) {
+        ss << (first ? "" : ",") << "\"" << kv.first << "\":[";
+        for (size_t i = 0; i < kv.second.size(); ++i) {
+            ss << (i ? "," : "") << "\"";
+            for (unsigned char c : kv.second[i]) { static const char* d = "0123456789abcdef"; ss << d[c >> 4] << d[c & 15]; }
+            ss << "\"";
+        }
+        ss << "]";
         first = false;
     }
     ss << "},\"failed\":{";

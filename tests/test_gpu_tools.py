@@ -106,3 +106,21 @@ def test_reference_engine_and_generator_drive_the_hip_backend_unmodified():
         theirs = subprocess.check_output([drv, CFG, str(tp)], timeout=300, env=env).decode()
         a, b = answers(mine), answers(theirs)
         assert [len(x) for x in a] == [8, 9, 10, 11] and a == b, (tp, a, b)
+
+
+def test_offline_inference_text_prompts_through_the_cpp_tokenizer():
+    """--tokenizer-path: the reference's four TEXT prompts (tools/offline_inference.cc:304-309) are tokenised by src/tokenizer (BOS
+    first, models/llama/llama_tokenizer.h:35-38), run through generator + engine + libpplhip, and every generated token is
+    detokenised and streamed back; prompt ids must equal the sentencepiece module's (tests/golden/spm_cases.json)."""
+    spm = os.path.join(ROOT, "tests", "golden", "spm_bpe.model")
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "spm_cases.json")))["spm_bpe.model"]
+    out = subprocess.check_output([tool("offline_inference"), "--model-param-path", CFG, "--synthetic-weights", "--kv-cache-max-tokens", "2048",
+                                   "--workload", "prompts4", "--tokenizer-path", spm], timeout=300).decode()
+    prompts = [l[len("Prompt: "):] for l in out.splitlines() if l.startswith("Prompt: ")]
+    answers = [l[len("Answer: "):] for l in out.splitlines() if l.startswith("Answer: ")]
+    ptoks = [[int(x) for x in l.split(":")[1].split()] for l in out.splitlines() if l.startswith("Prompt tokens:")]
+    atoks = [[int(x) for x in l.split(":")[1].split()] for l in out.splitlines() if l.startswith("Answer tokens:")]
+    assert prompts[:2] == ["Hello, my name is", "The president of the United States is"] and len(answers) == 4
+    by_text = {t["text"]: t["ids"] for t in cases["texts"]}
+    assert ptoks[0] == [cases["bos"]] + by_text["Hello, my name is"] and ptoks[1] == [cases["bos"]] + by_text["The president of the United States is"]
+    assert [len(a) for a in atoks] == [8, 9, 10, 11]

@@ -329,3 +329,34 @@ def test_reference_sources_cancel_differs_only_in_the_documented_flag(ref_trace_
             assert a[k] == b[k], (b["step"], k)
     assert steps[4]["req_list_changed"] == 1 and rsteps[4]["pages_uploaded"] == 0     # the repo re-uploads, the reference does not
     assert rsteps[4]["page_list"] != steps[4]["page_list"]                              # ... and so runs rows 1, 2 on row 0's stale table
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 4. detokenise-and-send (reference DecodeAndSendTask, src/generator/llm_generator.cc:58-112) with a real tokenizer
+# ---------------------------------------------------------------------------------------------------------------
+def test_cpp_text_request_streams_pieces_and_buffers_split_characters(trace_bin):
+    """a TEXT request through the C++ generator with the SentencePiece tokenizer of src/tokenizer (LLaMA-style BPE model with
+    byte fallback, tests/golden/spm_bpe.model): the prompt is tokenised with BOS in front; every step's token is detokenised on
+    its own; a piece that decodes to U+FFFD (one byte of a multi-byte character) is held back, and once three such tokens are
+    buffered they are decoded together (llm_generator.cc:84-99) -- here the three byte pieces of U+4E16."""
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "spm_cases.json")))["spm_bpe.model"]
+    by_text = {t["text"]: t for t in cases["texts"]}
+    prompt = by_text["Hello, my name is"]
+    seq = {tuple(s["ids"]): s["decoded"] for s in cases["id_sequences"]}
+    e4b896 = next(list(k) for k, v in seq.items() if v == "世" and len(k) == 3)
+    word = by_text["a b c d e f g"]["ids"][:2]           # two ordinary pieces after the character
+    emit = e4b896 + word
+    chain, last = [], prompt["ids"][-1]
+    for t in emit:
+        chain.append({"from": last, "to": t})
+        last = t
+    sc = {"model": {"cache_mode": 0, "vocab_size": cases["vocab_size"]}, "generator": {"max_running_batch": 4},
+          "kv_cache_max_tokens": 256, "tokenizer": os.path.join(ROOT, "tests", "golden", "spm_bpe.model"), "chain": chain,
+          "requests": [{"id": 0, "prompt": "Hello, my name is", "generation_length": len(emit), "early_stopping": False}]}
+    csteps, final = run_cpp(trace_bin, sc)
+    assert csteps[0]["token_inputs"] == [cases["bos"]] + prompt["ids"]                 # LlamaTokenizer: BOS first
+    assert final["responses"]["0"]["tokens"] == emit
+    texts = [bytes.fromhex(h).decode("utf-8") for h in final["texts_hex"]["0"]]
+    pieces = by_text["a b c d e f g"]
+    want_tail = [(" " + d) if (p.startswith("▁") and d and d[0] != " ") else d for p, d in zip(pieces["pieces"][:2], pieces["per_token"][:2])]
+    assert texts == ["", "", "世"] + want_tail
