@@ -128,6 +128,8 @@ def serving_leg(model_kw, args):
         json.dump(params, open(path, "w"))
         cmd = [exe, "--model-param-path", path, "--synthetic-weights", "--workload", "samples1024", "--num-requests", "1024",
                "--max-seq-len", "1024", "--max-running-batch", str(args.batch), "--max-tokens-per-step", "8192"]
+        if args.act_quant == 8:
+            cmd += ["--quant-method", "online_i8i8"]
         t0 = time.time()
         out = subprocess.run(cmd, capture_output=True, timeout=900)
         wall = time.time() - t0
@@ -223,6 +225,8 @@ def main():
     ap.add_argument("--kv-len", type=int, default=512)
     ap.add_argument("--weight-quant", type=int, default=8)
     ap.add_argument("--kv-quant", type=int, default=8)
+    ap.add_argument("--act-quant", type=int, default=0, choices=[0, 8],
+                    help="8 = the reference's --quant-method online_i8i8 (W8A8); NOT the configuration of the headline metric")
     ap.add_argument("--layers", type=int, default=0, help="debug only: override the layer count (result is then INVALID)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serving-leg", action="store_true", help="skip the samples_1024-shaped serving run (TTFT)")
@@ -269,7 +273,7 @@ def main():
     desc = P.make_desc(max_position=max(2048, total_len + 1), cache_quant_bit=args.kv_quant,
                        cache_quant_group=8 if args.kv_quant else 1, cache_layout=3, cache_mode=args.cache_mode,
                        page_size=16 if args.cache_mode else 0,
-                       weight_quant_bit=args.weight_quant, **mk)
+                       weight_quant_bit=args.weight_quant, act_quant_bit=args.act_quant, **mk)
     uid = None
     p2p_only = os.environ.get("PPLHIP_COMM") == "p2p"
     if world > 1 and not p2p_only:
@@ -423,9 +427,11 @@ def main():
             "metric": "decode tokens/sec, LLaMA-7B int8 (W8A16), max-running-batch 1024",
             "value": round(B * K / elapsed, 2), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "fp16 activations, int8 weights (W8A16), int8-g8 KV, fp32 accumulate",
+            "vs_baseline": None,
+            "dtype": ("int8 activations x int8 weights (online_i8i8, W8A8), int32 accumulate" if args.act_quant == 8 else
+                      "fp16 activations, int8 weights (W8A16), int8-g8 KV, fp32 accumulate"),
             "data": "synthetic (device-generated weights and KV history, random token ids)",
-            "config": {"workload": f"{args.model} W{args.weight_quant or 16}A16 decode, batch {B}, kv_len {args.kv_len}"
+            "config": {"workload": f"{args.model} W{args.weight_quant or 16}A{args.act_quant or 16} decode, batch {B}, kv_len {args.kv_len}"
                                    f"..{args.kv_len + K + W}, greedy top_k=1, cache_layout 3 / cache_mode {args.cache_mode}, "
                                    f"kv int{args.kv_quant or 16}", "global_batch": B, "seq_len": 1024,
                        "parallelism": f"tp{world}", "layers": desc.num_layers, "collectives": comm_mode},

@@ -61,6 +61,11 @@ typedef struct pplhip_model_desc {
     int32_t page_size;         /* tokens per page when cache_mode == 1 */
     int32_t weight_quant_bit;   /* 0 fp16 weights, 8 = W8A16 per-output-channel, 4 = W4A16 grouped */
     int32_t weight_quant_group; /* K-group of W4A16 (128); ignored otherwise */
+    int32_t act_quant_bit;      /* 0 = fp16 activations; 8 (with weight_quant_bit 8) = online_i8i8, the W8A8 mode of
+                                   src/backends/cuda/resource_manager.cc:51-52: per-token int8 activations in front of
+                                   every layer linear, int8 x int8 -> int32 on the matrix cores.  In this mode an fp16
+                                   [N,K] matrix handed to pplhip_rank_set_tensor for an int8 linear is quantised per
+                                   output row on the device ("online"). */
 } pplhip_model_desc;
 
 /* ---- context options: what CudaResourceManager::Init/InitTask take (resource_manager.cc:213-428) */
@@ -279,6 +284,14 @@ PPLHIP_API int pplhip_op_linear(void* stream, const void* x, const void* w, cons
 /* fused K3 + K10: W rows interleaved (gate_0, up_0, gate_1, up_1, ...), N = 2 * inter; y[M, N/2] = silu(gate) * up. */
 PPLHIP_API int pplhip_op_linear_swiglu(void* stream, const void* x, const void* w, const void* scale, int32_t wq_bit,
                                        int32_t group, int64_t M, int32_t N, int32_t K, void* y);
+
+/* online_i8i8 (W8A8, src/backends/cuda/resource_manager.cc:51-52).  Per-token activation quantisation: q[M,K] int8,
+ * sx[M] = max|x| / 127; per-output-row weight quantisation of an fp16 [N,K] matrix: q[N,K] int8, scale[N] fp16;
+ * y[m,n] = (sum_k xq * w as int32) * sx[m] * scale[n], rounded to fp16 (or kept fp32); swiglu as in pplhip_op_linear_swiglu. */
+PPLHIP_API int pplhip_op_quant_act(void* stream, const void* x, int64_t M, int32_t K, void* q, float* sx);
+PPLHIP_API int pplhip_op_quant_weight(void* stream, const void* w, int32_t N, int32_t K, void* q, void* scale);
+PPLHIP_API int pplhip_op_linear_i8(void* stream, const void* xq, const float* sx, const void* w, const void* scale, int64_t M,
+                                   int32_t N, int32_t K, void* y, int32_t out_fp32, int32_t swiglu);
 
 PPLHIP_API int pplhip_op_silu_mul(void* stream, const void* gate_up, int64_t T, int32_t inter, void* out);
 

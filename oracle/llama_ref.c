@@ -54,6 +54,7 @@ typedef struct ref_model_desc {
     int32_t max_position;
     int32_t cache_quant_bit, cache_quant_group, cache_layout, cache_mode, page_size;
     int32_t weight_quant_bit, weight_quant_group;
+    int32_t act_quant_bit; /* 8 = online_i8i8 (W8A8): activations quantised per token in front of every layer linear */
 } ref_model_desc;
 
 /* one step: ModelInput as the runtime sees it (src/engine/llm_engine.h:40-60, llm_engine.cc:29-111) */
@@ -75,6 +76,7 @@ typedef struct ref_linear {
     int8_t* w8;        /* qbit 8: [N,K] */
     uint8_t* w4;       /* qbit 4: [N,K/2], low nibble = even k, value = nibble - 8 */
     f16* scale;        /* qbit 8: [N]; qbit 4: [N, K/group] */
+    int32_t a8;        /* qbit 8 only: int8 activations (online_i8i8) */
 } ref_linear;
 
 typedef struct ref_layer {
@@ -186,6 +188,7 @@ REF_API ref_model* ref_create(const ref_model_desc* d, int tp_size, int tp_rank)
         linear_alloc(&L->wo, hd, m->H * m->D, q, g);
         linear_alloc(&L->w13, 2 * m->inter, hd, q, g);
         linear_alloc(&L->w2, hd, m->inter, q, g);
+        if (d->act_quant_bit == 8 && q == 8) L->wqkv.a8 = L->wo.a8 = L->w13.a8 = L->w2.a8 = 1;
     }
     linear_alloc(&m->output, m->vocab_local, hd, 0, 0);
     m->rope = (float*)malloc((size_t)d->max_position * m->D * sizeof(float));
@@ -237,9 +240,24 @@ static int find_tensor(ref_model* m, const char* name, void** ptr, uint64_t* byt
     return -1;
 }
 
+static ref_linear* find_w8_linear(ref_model* m, const char* name) {
+    int l = -1; char rest[128];
+    if (sscanf(name, "layers.%d.%127s", &l, rest) != 2 || l < 0 || l >= m->d.num_layers) return NULL;
+    ref_layer* L = &m->layers[l];
+    ref_linear* lin = !strcmp(rest, "attention.wqkv.weight") ? &L->wqkv : !strcmp(rest, "attention.wo.weight") ? &L->wo
+                    : !strcmp(rest, "feed_forward.w13.weight") ? &L->w13 : !strcmp(rest, "feed_forward.w2.weight") ? &L->w2 : NULL;
+    return lin && lin->qbit == 8 ? lin : NULL;
+}
+
 REF_API int ref_set_tensor(ref_model* m, const char* name, const void* data, uint64_t bytes) {
     void* p; uint64_t b;
     if (find_tensor(m, name, &p, &b)) return -6;
+    /* "online" quantisation: an fp16 matrix handed to an int8 linear is quantised per output row on the way in */
+    ref_linear* lin = find_w8_linear(m, name);
+    if (lin && bytes == (uint64_t)lin->N * lin->K * 2) {
+        ref_quant_weight_rows((const f16*)data, lin->N, lin->K, lin->w8, lin->scale);
+        return 0;
+    }
     if (b != bytes) return -2;
     memcpy(p, data, bytes);
     return 0;
@@ -379,8 +397,12 @@ static inline float dot_f32(const float* a, const float* b, int n) {
  *   W8A16          : y = scale[n] * sum_k x * int8            (per-output-channel symmetric)
  *   W4A16 group g  : y = sum_G scale[n,G] * sum_{k in G} x * (nibble-8)
  * out_fp32 = 0 rounds the result to fp16 (activations), 1 keeps fp32 (logits, llm_engine.cc:207-222). */
+REF_API void ref_quant_act_rows(const float* x, int64_t M, int K, int8_t* q, float* sx);
+static void linear_fwd_a8(const ref_linear* l, const float* x, int64_t M, float* y, int out_fp32);
+
 REF_API void ref_linear_fwd(const ref_linear* l, const float* x, int64_t M, float* y, int out_fp32) {
     const int N = l->N, K = l->K;
+    if (l->qbit == 8 && l->a8) { linear_fwd_a8(l, x, M, y, out_fp32); return; }
 #pragma omp parallel
     {
         float* wrow = (float*)malloc(sizeof(float) * K);
@@ -418,6 +440,72 @@ REF_API void ref_linear_fwd(const ref_linear* l, const float* x, int64_t M, floa
         }
         free(wrow);
     }
+}
+
+/* online_i8i8 (W8A8; the mode src/backends/cuda/resource_manager.cc:51-52 hands to ppl.nn, whose kernels are not in
+ * the tree -- the arithmetic below is this build's specification, parity with the reference unpinned):
+ *   per token row   amax = max|x|, sx = amax / 127 (fp32), q = clamp(rint(x * (127 / amax)), -127, 127)
+ *   per weight row  scale = fp16(max|w| / 127), q = clamp(rint(w / scale), -127, 127)      (at load time)
+ *   y[m,n] = fp16( (float)(sum_k qx*qw as int32) * sx[m] * scale[n] )                    (multiplied in that order) */
+REF_API void ref_quant_act_rows(const float* x, int64_t M, int K, int8_t* q, float* sx) {
+#pragma omp parallel for
+    for (int64_t m = 0; m < M; ++m) {
+        const float* xr = x + m * K;
+        float amax = 0.f;
+        for (int k = 0; k < K; ++k) { float a = fabsf(xr[k]); if (a > amax) amax = a; }
+        const float inv = amax > 0.f ? 127.0f / amax : 0.f;
+        sx[m] = amax / 127.0f;
+        for (int k = 0; k < K; ++k) {
+            float v = rintf(xr[k] * inv);
+            v = v > 127.f ? 127.f : (v < -127.f ? -127.f : v);
+            q[m * K + k] = (int8_t)v;
+        }
+    }
+}
+
+REF_API void ref_quant_weight_rows(const f16* w, int N, int K, int8_t* q, f16* scale) {
+#pragma omp parallel for
+    for (int n = 0; n < N; ++n) {
+        const f16* wr = w + (size_t)n * K;
+        float amax = 0.f;
+        for (int k = 0; k < K; ++k) { float a = fabsf(h2f(wr[k])); if (a > amax) amax = a; }
+        const f16 sh = f2h(amax / 127.0f);
+        scale[n] = sh;
+        const float s = h2f(sh) > 0.f ? h2f(sh) : 1.0f;
+        for (int k = 0; k < K; ++k) {
+            float v = rintf(h2f(wr[k]) / s);
+            v = v > 127.f ? 127.f : (v < -127.f ? -127.f : v);
+            q[(size_t)n * K + k] = (int8_t)v;
+        }
+    }
+}
+
+static void linear_fwd_a8(const ref_linear* l, const float* x, int64_t M, float* y, int out_fp32) {
+    const int N = l->N, K = l->K;
+    int8_t* xq = (int8_t*)malloc((size_t)M * K);
+    float* sx = (float*)malloc(sizeof(float) * M);
+    ref_quant_act_rows(x, M, K, xq, sx);
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; ++n) {
+        const int8_t* w = l->w8 + (size_t)n * K;
+        const float sw = h2f(l->scale[n]);
+        for (int64_t m = 0; m < M; ++m) {
+            const int8_t* xr = xq + m * K;
+            int32_t acc = 0;
+            for (int k = 0; k < K; ++k) acc += (int32_t)xr[k] * (int32_t)w[k];
+            const float v = ((float)acc * sx[m]) * sw;
+            y[m * N + n] = out_fp32 ? v : rh(v);
+        }
+    }
+    free(xq); free(sx);
+}
+
+/* stand-alone int8 x int8 linear for operator tests */
+REF_API void ref_linear_i8_raw(const float* x, const int8_t* w, const f16* scale, int64_t M, int N, int K, float* y,
+                               int out_fp32) {
+    ref_linear l; memset(&l, 0, sizeof(l));
+    l.N = N; l.K = K; l.qbit = 8; l.a8 = 1; l.scale = (f16*)scale; l.w8 = (int8_t*)w;
+    ref_linear_fwd(&l, x, M, y, out_fp32);
 }
 
 /* stand-alone form for operator tests */

@@ -19,7 +19,7 @@ class ModelDesc(C.Structure):
                 ("norm_eps", C.c_float), ("rope_theta", C.c_float), ("max_position", C.c_int32),
                 ("cache_quant_bit", C.c_int32), ("cache_quant_group", C.c_int32), ("cache_layout", C.c_int32),
                 ("cache_mode", C.c_int32), ("page_size", C.c_int32), ("weight_quant_bit", C.c_int32),
-                ("weight_quant_group", C.c_int32)]
+                ("weight_quant_group", C.c_int32), ("act_quant_bit", C.c_int32)]
 
 
 class Step(C.Structure):
@@ -33,7 +33,7 @@ class Step(C.Structure):
 def make_desc(**kw):
     d = ModelDesc()
     defaults = dict(norm_eps=1e-5, rope_theta=10000.0, max_position=4096, cache_quant_bit=0, cache_quant_group=1,
-                    cache_layout=3, cache_mode=0, page_size=0, weight_quant_bit=0, weight_quant_group=128)
+                    cache_layout=3, cache_mode=0, page_size=0, weight_quant_bit=0, weight_quant_group=128, act_quant_bit=0)
     defaults.update(kw)
     if defaults.get("num_kv_heads") is None:
         defaults["num_kv_heads"] = defaults["num_heads"]
@@ -109,6 +109,9 @@ def lib():
         L.ref_rmsnorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         L.ref_linear_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int,
                                      C.c_void_p, C.c_int]
+        L.ref_linear_i8_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.ref_quant_act_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+        L.ref_quant_weight_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.ref_silu_mul.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         L.ref_rope_kv_write.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(ModelDesc), C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,

@@ -1,0 +1,306 @@
+// online_i8i8 (W8A8) linear layers: the quant method src/backends/cuda/resource_manager.cc:51-52 hands to ppl.nn.
+//   activations  per token row:   sx = max|x| / 127 (fp32), q = clamp(rint(x * (127 / max|x|)))           quant_act_kernel
+//   weights      per output row:  scale = fp16(max|w| / 127), q = clamp(rint(w / scale))   (once, at load) quant_weight_kernel
+//   y[m,n] = fp16( (float)(sum_k qx * qw) * sx[m] * scale[n] ),  the sum exact in int32 on the matrix cores
+// Oracle: linear_fwd_a8 / ref_quant_act_rows / ref_quant_weight_rows (oracle/llama_ref.c) -- integer accumulation makes
+// the GEMM itself bit-exact against it; only the fp16 rounding of the two fp32 multiplies is left, done in the same order.
+//
+// Tile kernel (M > 32, K % 128 == 0): block tile 128 (n) x 128 (m) x 128 (k) int8, 4 waves as 2 x 2, each 64 x 64 =
+// 4 x 4 tiles of v_mfma_i32_16x16x64_i8 (weights = A operand, so a lane owns 4 consecutive n of one activation row).
+// Both operands go global -> LDS by DMA into [row][128 B] tiles whose 16-byte chunk index is XOR-swizzled with
+// (row >> 1) & 7 on the source address and on the fragment reads (same scheme as the fp16 activation tile of k_gemm_dev.h).
+// Two LDS stages (64 KiB -> two blocks per CU), one barrier per K tile.
+// Skinny / generic kernel (any M, K % 16 == 0): one block per 16 weight rows, waves split K, weights straight from HBM
+// into the MFMA A operand, activations (L2 resident) into B; grid.y walks 32-row activation groups.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "k_gemm_dev.h"
+
+namespace pplhip {
+
+typedef int i4v __attribute__((ext_vector_type(4)));
+
+constexpr int I_BN = 128, I_BM = 128, I_BK = 128;
+
+__device__ __forceinline__ float block_max_256(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__device__ __forceinline__ int q8(float v) {
+    v = rintf(v);
+    v = fminf(fmaxf(v, -127.f), 127.f);
+    return (int)v;
+}
+
+// one block per row; x [M, ldx] fp16 (K valid), q [M, ldq] int8 (columns K..ldq-1 zero), sx [M]
+__global__ __launch_bounds__(256) void quant_act_kernel(const uint16_t* __restrict__ x, int K, int64_t ldx, int8_t* __restrict__ q,
+                                                        int64_t ldq, float* __restrict__ sx) {
+    __shared__ float red[4];
+    const int64_t m = blockIdx.x;
+    const uint16_t* xr = x + m * ldx;
+    int8_t* qr = q + m * ldq;
+    const int K8 = K >> 3;
+    float amax = 0.f;
+    for (int i = threadIdx.x; i < K8; i += 256) {
+        const h8 v = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(xr + i * 8));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf((float)v[j]));
+    }
+    for (int k = K8 * 8 + threadIdx.x; k < K; k += 256) amax = fmaxf(amax, fabsf(h2f(xr[k])));
+    amax = block_max_256(amax, red);
+    const float inv = amax > 0.f ? 127.0f / amax : 0.f;
+    if (threadIdx.x == 0) sx[m] = amax / 127.0f;
+    for (int i = threadIdx.x; i < K8; i += 256) {
+        const h8 v = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(xr + i * 8));
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lo |= (uint32_t)(q8((float)v[j] * inv) & 0xff) << (8 * j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hi |= (uint32_t)(q8((float)v[4 + j] * inv) & 0xff) << (8 * j);
+        *reinterpret_cast<uint2*>(qr + i * 8) = make_uint2(lo, hi);
+    }
+    for (int k = K8 * 8 + threadIdx.x; k < K; k += 256) qr[k] = (int8_t)q8(h2f(xr[k]) * inv);
+    for (int64_t k = K + threadIdx.x; k < ldq; k += 256) qr[k] = 0;
+}
+
+// one block per weight row; w [N, K] fp16 -> q [N, ldq] int8 (pad columns zero) + scale [N] fp16
+__global__ __launch_bounds__(256) void quant_weight_kernel(const uint16_t* __restrict__ w, int K, int8_t* __restrict__ q, int64_t ldq,
+                                                           uint16_t* __restrict__ scale) {
+    __shared__ float red[4];
+    const int64_t n = blockIdx.x;
+    const uint16_t* wr = w + n * K;
+    int8_t* qr = q + n * ldq;
+    float amax = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) amax = fmaxf(amax, fabsf(h2f(wr[k])));
+    amax = block_max_256(amax, red);
+    const uint16_t sh = f2h(amax / 127.0f);
+    if (threadIdx.x == 0) scale[n] = sh;
+    const float s = h2f(sh) > 0.f ? h2f(sh) : 1.0f;
+    for (int k = threadIdx.x; k < K; k += 256) qr[k] = (int8_t)q8(h2f(wr[k]) / s);  // IEEE division (hipcc default: correctly rounded)
+    for (int64_t k = K + threadIdx.x; k < ldq; k += 256) qr[k] = 0;
+}
+
+template <int EPI>
+__device__ __forceinline__ void store4_i8(void* yv, int64_t ldy, int64_t m, int n, i4v acc, float sxm, h4 sh) {
+    store4<EPI>(yv, ldy, m, n, ((float)acc[0] * sxm) * (float)sh[0], ((float)acc[1] * sxm) * (float)sh[1],
+                ((float)acc[2] * sxm) * (float)sh[2], ((float)acc[3] * sxm) * (float)sh[3]);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_i8_kernel(const int8_t* __restrict__ xq, const float* __restrict__ sx,
+                                                         const int8_t* __restrict__ w, const uint16_t* __restrict__ scale, int64_t M,
+                                                         int N, int K, void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem_i8[];  // 2 x (X 16 KiB + W 16 KiB)
+    constexpr int TILE = I_BM * I_BK;                               // bytes of one operand tile
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;  // the M tiles of one weight tile run on one XCD (block b -> XCD b % 8)
+    const int nt = xcd + 8 * (slot / m_tiles);
+    const int mt = slot % m_tiles;
+    if (nt >= n_tiles) return;
+    const int n0 = nt * I_BN;
+    const int64_t m0 = (int64_t)mt * I_BM;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int wn = wave & 1, wm = wave >> 1;
+
+    const int8_t* xsrc[4];
+    const int8_t* wsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = j * 256 + tid, row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
+        int64_t m = m0 + row;
+        if (m >= M) m = M - 1;
+        int n = n0 + row;
+        if (n >= N) n = N - 1;
+        xsrc[j] = xq + m * K + c * 16;
+        wsrc[j] = w + (int64_t)n * K + c * 16;
+    }
+    const uint32_t xdst = __builtin_amdgcn_readfirstlane(lds_addr(smem_i8) + wave * 1024);
+    const uint32_t wdst = xdst + 2 * TILE;
+    auto issue = [&](int stage, int k0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(xsrc[j] + k0, xdst + stage * TILE + j * 4096);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(wsrc[j] + k0, wdst + stage * TILE + j * 4096);
+    };
+
+    i4v acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = i4v{0, 0, 0, 0};
+
+    const int ktiles = K / I_BK;
+    issue(0, 0);
+    for (int t = 0; t < ktiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < ktiles) issue((t + 1) & 1, (t + 1) * I_BK);
+        const char* xs = smem_i8 + (t & 1) * TILE;
+        const char* ws = smem_i8 + 2 * TILE + (t & 1) * TILE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            i4v a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wn * 64 + i * 16 + l15;
+                a[i] = *reinterpret_cast<const i4v*>(ws + row * I_BK + g_swz(row, ks * 4 + kq) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wm * 64 + j * 16 + l15;
+                b[j] = *reinterpret_cast<const i4v*>(xs + row * I_BK + g_swz(row, ks * 4 + kq) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t m = m0 + wm * 64 + j * 16 + l15;
+        if (m >= M) continue;
+        const float sxm = sx[m];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + kq * 4;
+            if (n >= N) continue;
+            const h4 sh = __builtin_bit_cast(h4, *reinterpret_cast<const uint2*>(scale + n));
+            store4_i8<EPI>(yv, ldy, m, n, acc[i][j], sxm, sh);
+        }
+    }
+}
+
+// skinny / generic: block = NW waves = NW K slices of 16 weight rows; MT = 16-row activation tiles per block (grid.y walks M)
+template <int MT, int EPI, int NW>
+__global__ __launch_bounds__(NW * 64) void gemv_i8_kernel(const int8_t* __restrict__ xq, const float* __restrict__ sx,
+                                                          const int8_t* __restrict__ w, const uint16_t* __restrict__ scale, int64_t M, int N,
+                                                          int K, void* __restrict__ yv, int64_t ldy) {
+    __shared__ __attribute__((aligned(16))) int red[NW - 1][MT][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int64_t mbase = (int64_t)blockIdx.y * (MT * 16);
+    int n = n0 + l15;
+    if (n >= N) n = N - 1;
+    const int steps = (K + 63) / 64;  // one wave-load = 16 rows x 64 bytes
+    const int per = (steps + NW - 1) / NW;
+    const int s_begin = wave * per, s_end = (s_begin + per < steps) ? s_begin + per : steps;
+    const int8_t* wrow = w + (int64_t)n * K;
+    const int8_t* xrow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int64_t m = mbase + mt * 16 + l15;
+        if (m >= M) m = M - 1;
+        xrow[mt] = xq + m * K;
+    }
+    i4v acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = i4v{0, 0, 0, 0};
+    constexpr int U = 8;  // wave-loads of weights in flight (the block streams its rows once: bytes in flight = bandwidth)
+    for (int st0 = s_begin; st0 < s_end; st0 += U) {
+        i4v wr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = (st0 + u) * 64 + kq * 16;
+            const bool ok = st0 + u < s_end && k < K;  // K % 16 == 0 (launcher)
+            wr[u] = ok ? *reinterpret_cast<const i4v*>(wrow + k) : i4v{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = (st0 + u) * 64 + kq * 16;
+            const bool ok = st0 + u < s_end && k < K;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const i4v xr = ok ? *reinterpret_cast<const i4v*>(xrow[mt] + k) : i4v{0, 0, 0, 0};
+                acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wr[u], xr, acc[mt], 0, 0, 0);
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<i4v*>(red[wave - 1][mt][lane]) = acc[mt];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int nn = n0 + kq * 4;
+        if (nn < N) {
+            const h4 sh = __builtin_bit_cast(h4, *reinterpret_cast<const uint2*>(scale + nn));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                i4v v = acc[mt];
+#pragma unroll
+                for (int ww = 0; ww < NW - 1; ++ww) v += *reinterpret_cast<const i4v*>(red[ww][mt][lane]);
+                const int64_t m = mbase + mt * 16 + l15;
+                if (m >= M) continue;
+                store4_i8<EPI>(yv, ldy, m, nn, v, sx[m], sh);
+            }
+        }
+    }
+}
+
+hipError_t launch_quant_act(hipStream_t s, const uint16_t* x, int64_t M, int K, int64_t ldx, int8_t* q, int64_t ldq, float* sx) {
+    if (M == 0) return hipSuccess;
+    if (K % 8 || ldx % 8 || ldq % 8 || ldq < K) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(quant_act_kernel, dim3((unsigned)M), dim3(256), 0, s, x, K, ldx, q, ldq, sx);
+    return hipGetLastError();
+}
+
+hipError_t launch_quant_weight(hipStream_t s, const uint16_t* w, int N, int K, int8_t* q, int64_t ldq, uint16_t* scale) {
+    if (N == 0) return hipSuccess;
+    if (ldq < K) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(quant_weight_kernel, dim3((unsigned)N), dim3(256), 0, s, w, K, q, ldq, scale);
+    return hipGetLastError();
+}
+
+hipError_t launch_linear_i8(hipStream_t s, const int8_t* xq, const float* sx, const int8_t* w, const uint16_t* scale, int64_t M, int N,
+                            int K, void* y, int64_t ldy, bool out_fp32, bool swiglu) {
+    if (M == 0) return hipSuccess;
+    if (swiglu && out_fp32) return hipErrorInvalidValue;
+    if (N % 4 || ldy % 4 || K % 16) return hipErrorInvalidValue;
+    const int epi = swiglu ? EPI_SWIGLU : (out_fp32 ? EPI_F32 : EPI_F16);
+    static const bool force_generic = getenv("PPLHIP_GEMM_GENERIC") != nullptr;
+    if (M > 32 && K % I_BK == 0 && !force_generic) {
+        const int n_tiles = (N + I_BN - 1) / I_BN, m_tiles = (int)((M + I_BM - 1) / I_BM);
+        const size_t lds = 4 * (size_t)I_BM * I_BK;
+        static bool attr_dev[64] = {false};  // per device (see launch_linear)
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!attr_dev[dev & 63]) {
+            (void)hipFuncSetAttribute((const void*)gemm_i8_kernel<EPI_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gemm_i8_kernel<EPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gemm_i8_kernel<EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_dev[dev & 63] = true;
+        }
+        dim3 grid((unsigned)((n_tiles + 7) / 8 * 8 * m_tiles));
+#define LT(E) hipLaunchKernelGGL((gemm_i8_kernel<E>), grid, dim3(256), lds, s, xq, sx, w, scale, M, N, K, y, ldy, n_tiles, m_tiles)
+        if (epi == EPI_F32) LT(EPI_F32); else if (epi == EPI_F16) LT(EPI_F16); else LT(EPI_SWIGLU);
+#undef LT
+        return hipGetLastError();
+    }
+    const int nblk = (N + 15) / 16;
+    if (M <= 16) {
+        dim3 grid((unsigned)nblk, 1);
+#define LV(E) do { if (nblk <= 1024) hipLaunchKernelGGL((gemv_i8_kernel<1, E, 8>), grid, dim3(512), 0, s, xq, sx, w, scale, M, N, K, y, ldy); \
+                   else hipLaunchKernelGGL((gemv_i8_kernel<1, E, 4>), grid, dim3(256), 0, s, xq, sx, w, scale, M, N, K, y, ldy); } while (0)
+        if (epi == EPI_F32) LV(EPI_F32); else if (epi == EPI_F16) LV(EPI_F16); else LV(EPI_SWIGLU);
+#undef LV
+        return hipGetLastError();
+    }
+    dim3 grid((unsigned)nblk, (unsigned)((M + 31) / 32));
+#define LV(E) hipLaunchKernelGGL((gemv_i8_kernel<2, E, 4>), grid, dim3(256), 0, s, xq, sx, w, scale, M, N, K, y, ldy)
+    if (epi == EPI_F32) LV(EPI_F32); else if (epi == EPI_F16) LV(EPI_F16); else LV(EPI_SWIGLU);
+#undef LV
+    return hipGetLastError();
+}
+
+}  // namespace pplhip

@@ -53,6 +53,14 @@ hipError_t launch_attn_decode_gqa(hipStream_t s, const uint16_t* qkv, const KvAd
 hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const uint16_t* scale, int wq_bit, int group,
                          int64_t M, int N, int K, void* y, int64_t ldy, bool out_fp32, float* ws = nullptr, size_t ws_bytes = 0,
                          bool swiglu = false);
+// ---- k_gemm_i8.hip: online_i8i8 (W8A8) ------------------------------------------------------------
+// per-token int8 activations: q [M, ldq] (columns K..ldq-1 zeroed), sx [M] = max|x| / 127
+hipError_t launch_quant_act(hipStream_t s, const uint16_t* x, int64_t M, int K, int64_t ldx, int8_t* q, int64_t ldq, float* sx);
+// per-output-row int8 weights from an fp16 [N, K] matrix: q [N, ldq], scale [N] fp16
+hipError_t launch_quant_weight(hipStream_t s, const uint16_t* w, int N, int K, int8_t* q, int64_t ldq, uint16_t* scale);
+// y[M,N] = fp16/fp32( (sum_k xq * w) * sx[m] * scale[n] ); K = row stride of xq and w (K % 16 == 0)
+hipError_t launch_linear_i8(hipStream_t s, const int8_t* xq, const float* sx, const int8_t* w, const uint16_t* scale, int64_t M, int N,
+                            int K, void* y, int64_t ldy, bool out_fp32, bool swiglu);
 // dst row r = src row perm(r): r even -> r/2 (gate), r odd -> half + r/2 (up).  row_bytes % 4 == 0.
 hipError_t launch_interleave_rows(hipStream_t s, const void* src, void* dst, int rows, int64_t row_bytes);
 

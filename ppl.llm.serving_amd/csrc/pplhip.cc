@@ -85,6 +85,8 @@ struct Rank {
     // activations
     uint16_t *h = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *part = nullptr, *part2 = nullptr, *gu = nullptr,
              *act = nullptr, *hn = nullptr;
+    int8_t* xq = nullptr;  // online_i8i8: int8 activations [cap_T, max row] and per-token scales
+    float* sx = nullptr;
     float* logits_local = nullptr;  // [B, V/tp] (tp > 1)
     float* logits_gather = nullptr; // [tp, B, V/tp]
     float* logits = nullptr;        // [B, V]
@@ -167,6 +169,9 @@ int fail(pplhip_ctx* c, int rank, int code, const std::string& msg) {
             return fail(c, r, PPLHIP_DEVICE_RUNTIME_ERROR, std::string(#expr) + ": " + ncclGetErrorString(e__));     \
     } while (0)
 
+// k-tile the padded row stride of w2 / the SwiGLU output is rounded to: 64 (fp16-activation tile GEMM), 128 (int8 x int8)
+static int k_tile(const pplhip_model_desc& d) { return d.act_quant_bit == 8 ? 128 : 64; }
+
 int dev_alloc(pplhip_ctx* c, int r, void** p, uint64_t bytes) {
     *p = nullptr;
     if (bytes == 0) return 0;
@@ -178,7 +183,8 @@ int dev_alloc(pplhip_ctx* c, int r, void** p, uint64_t bytes) {
 
 int linear_alloc(pplhip_ctx* c, int r, Linear* l, int N, int K, int qbit, int group, bool pad_k = false) {
     l->N = N; l->K = K; l->qbit = qbit; l->group = group;
-    l->Kp = (pad_k && qbit != 4) ? (K + 63) / 64 * 64 : K;
+    const int kt = k_tile(c->d);
+    l->Kp = (pad_k && qbit != 4) ? (K + kt - 1) / kt * kt : K;
     int rc = dev_alloc(c, r, &l->w, l->alloc_bytes());
     if (rc) return rc;
     if (l->Kp != K) {
@@ -397,7 +403,7 @@ int p2p_check(pplhip_ctx* c, int rank) {
 
 extern "C" {
 
-int pplhip_version(void) { return (1 << 16) | 0; }
+int pplhip_version(void) { return (1 << 16) | 1; }  // 1.1: pplhip_model_desc.act_quant_bit, comm_* and W8A8 operator entry points
 
 int pplhip_device_count(void) {
     int n = 0;
@@ -487,6 +493,7 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
     if (d.cache_layout < 0 || d.cache_layout > 3 || d.cache_mode < 0 || d.cache_mode > 1) return bad("cache layout/mode");
     if (d.cache_mode == 1 && d.page_size <= 0) return bad("page_size");
     if (d.weight_quant_bit != 0 && d.weight_quant_bit != 8 && d.weight_quant_bit != 4) return bad("weight quant");
+    if (d.act_quant_bit != 0 && !(d.act_quant_bit == 8 && d.weight_quant_bit == 8)) return bad("act quant (8 needs weight_quant_bit 8)");
     if (opts->max_running_batch <= 0 || opts->max_tokens_per_step <= 0 || d.max_position <= 0) return bad("limits");
     c->D = d.hidden_dim / d.num_heads;
     c->H = d.num_heads / tp;
@@ -639,7 +646,11 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
             *R.p2p_status = 0;
             ALLOC(R.d_flag, 64);
         }
-        const int inter_p = (d.weight_quant_bit != 4) ? (c->inter + 63) / 64 * 64 : c->inter;  // = layers[*].w2.Kp
+        const int inter_p = (d.weight_quant_bit != 4) ? (c->inter + k_tile(d) - 1) / k_tile(d) * k_tile(d) : c->inter;  // = layers[*].w2.Kp
+        if (d.act_quant_bit == 8) {  // online_i8i8: the int8 copy of whatever feeds the next linear + its per-token scales
+            ALLOC(R.xq, (uint64_t)cap_T * std::max(std::max(hd, c->H * c->D), inter_p));
+            ALLOC(R.sx, (uint64_t)cap_T * 4);
+        }
         ALLOC(R.act, (uint64_t)cap_T * inter_p * 2);
         if (inter_p != c->inter) HIPCK(cp, r, hipMemset(R.act, 0, (uint64_t)cap_T * inter_p * 2));  // pad columns stay zero
         ALLOC(R.hn, (uint64_t)cap_B * hd * 2);
@@ -729,9 +740,28 @@ int pplhip_rank_set_tensor(pplhip_ctx* c, int rank, const char* name, const void
     void* p; uint64_t b;
     Linear* lin = nullptr;
     if (!find_tensor(c, R, name, &p, &b, &lin)) return fail(c, rank, PPLHIP_NOT_FOUND, std::string("unknown tensor ") + name);
+    const char* w13 = strstr(name, "feed_forward.w13.");
+    if (lin && lin->qbit == 8 && c->d.act_quant_bit == 8 && bytes == (uint64_t)lin->N * lin->K * 2) {
+        // online_i8i8 "online" half: an fp16 [N, K] matrix for an int8 linear is quantised per output row on the device
+        HIPCK(c, rank, hipSetDevice(R.device));
+        void *tmp = nullptr, *tmp2 = nullptr;
+        HIPCK(c, rank, hipMalloc(&tmp, bytes));
+        hipError_t e = hipMemcpy(tmp, data, bytes, hipMemcpyHostToDevice);
+        const uint16_t* src = (const uint16_t*)tmp;
+        if (e == hipSuccess && w13) {  // rows interleaved (gate_i, up_i) first: the per-row quantisation moves with the row
+            e = hipMalloc(&tmp2, bytes);
+            if (e == hipSuccess) e = launch_interleave_rows(R.stream, tmp, tmp2, lin->N, (int64_t)lin->K * 2);
+            src = (const uint16_t*)tmp2;
+        }
+        if (e == hipSuccess) e = launch_quant_weight(R.stream, src, lin->N, lin->K, (int8_t*)lin->w, lin->Kp, lin->scale);
+        if (e == hipSuccess) e = hipStreamSynchronize(R.stream);
+        hipFree(tmp);
+        if (tmp2) hipFree(tmp2);
+        if (e != hipSuccess) return fail(c, rank, PPLHIP_DEVICE_RUNTIME_ERROR, std::string("online weight quantisation: ") + hipGetErrorString(e));
+        return 0;
+    }
     if (b != bytes) return fail(c, rank, PPLHIP_INVALID_VALUE, std::string("tensor ") + name + ": got " + std::to_string(bytes) + " bytes, want " + std::to_string(b));
     HIPCK(c, rank, hipSetDevice(R.device));
-    const char* w13 = strstr(name, "feed_forward.w13.");
     if (w13) {
         // the container stores w13 as [gate rows | up rows]; on the device the rows are interleaved (gate_i, up_i) so
         // that the GEMM epilogue can apply SwiGLU (kernels.h: launch_linear swiglu)
@@ -1032,6 +1062,19 @@ struct Chunk {
     int64_t b0, bn, t0, tn, nd;
 };
 
+// one layer linear over a chunk: fp16 activations straight into the (weight-only quantised) GEMM, or -- online_i8i8 -- quantised
+// per token first and multiplied in int8.  x rows have stride l.Kp.
+static int layer_linear(pplhip_ctx* c, int rank, const Linear& l, const uint16_t* x, int64_t M, void* y, int64_t ldy, bool swiglu) {
+    Rank& R = c->ranks[rank];
+    if (c->d.act_quant_bit == 8) {
+        HIPCK(c, rank, launch_quant_act(R.stream, x, M, l.Kp, l.Kp, R.xq, l.Kp, R.sx));
+        HIPCK(c, rank, launch_linear_i8(R.stream, R.xq, R.sx, (const int8_t*)l.w, l.scale, M, l.N, l.Kp, y, ldy, false, swiglu));
+        return 0;
+    }
+    HIPCK(c, rank, launch_linear(R.stream, x, l.w, l.scale, l.qbit, l.group, M, l.N, l.Kp, y, ldy, false, R.gemm_ws, R.gemm_ws_bytes, swiglu));
+    return 0;
+}
+
 // attention block of layer l for one chunk: (Skip)RMSNorm -> wqkv -> RoPE + KV write -> attention -> wo (partial sums)
 static int layer_attention_part(pplhip_ctx* c, int rank, int l, const Chunk& k, const uint16_t* pending, int split, int threads) {
     Rank& R = c->ranks[rank];
@@ -1046,8 +1089,7 @@ static int layer_attention_part(pplhip_ctx* c, int rank, int l, const Chunk& k, 
     HIPCK(c, rank, launch_rmsnorm(s, h, pending ? pending + k.t0 * hd : nullptr, L.attn_norm, d.norm_eps, k.tn, hd, nullptr, xn,
                                   pending ? h : nullptr));
     prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-    HIPCK(c, rank, launch_linear(s, xn, L.wqkv.w, L.wqkv.scale, L.wqkv.qbit, L.wqkv.group, k.tn, L.wqkv.N, L.wqkv.K,
-                                 R.qkv + k.t0 * nqkv, L.wqkv.N, false, R.gemm_ws, R.gemm_ws_bytes));
+    { int rc = layer_linear(c, rank, L.wqkv, xn, k.tn, R.qkv + k.t0 * nqkv, L.wqkv.N, false); if (rc) return rc; }
     prof_end(R, &ev);
     const KvAddr kv = make_kv_addr(d, Hkv, D, R.kv_tokens, R.kv_cache, R.kv_scale, l);
     HIPCK(c, rank, launch_rope_kv_write(s, R.qkv, R.rope, kv, d.cache_quant_bit, d.cache_quant_group, R.d_seq, R.d_sp, R.d_ci,
@@ -1069,8 +1111,7 @@ static int layer_attention_part(pplhip_ctx* c, int rank, int l, const Chunk& k, 
         prof_end(R, &ev);
     }
     prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-    HIPCK(c, rank, launch_linear(s, R.att + k.t0 * (int64_t)H * D, L.wo.w, L.wo.scale, L.wo.qbit, L.wo.group, k.tn, L.wo.N, L.wo.K,
-                                 R.part + k.t0 * hd, hd, false, R.gemm_ws, R.gemm_ws_bytes));
+    { int rc = layer_linear(c, rank, L.wo, R.att + k.t0 * (int64_t)H * D, k.tn, R.part + k.t0 * hd, hd, false); if (rc) return rc; }
     prof_end(R, &ev);
     return 0;
 }
@@ -1088,12 +1129,10 @@ static int layer_ffn_part(pplhip_ctx* c, int rank, int l, const Chunk& k) {
     uint16_t* act = R.act + k.t0 * (int64_t)L.w2.Kp;
     HIPCK(c, rank, launch_rmsnorm(s, h, R.part + k.t0 * hd, L.ffn_norm, d.norm_eps, k.tn, hd, nullptr, xn, h));
     prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-    HIPCK(c, rank, launch_linear(s, xn, L.w13.w, L.w13.scale, L.w13.qbit, L.w13.group, k.tn, L.w13.N, L.w13.K, act, L.w2.Kp, false,
-                                 R.gemm_ws, R.gemm_ws_bytes, /*swiglu=*/true));
+    { int rc = layer_linear(c, rank, L.w13, xn, k.tn, act, L.w2.Kp, /*swiglu=*/true); if (rc) return rc; }
     prof_end(R, &ev);
     prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-    HIPCK(c, rank, launch_linear(s, act, L.w2.w, L.w2.scale, L.w2.qbit, L.w2.group, k.tn, L.w2.N, L.w2.Kp, R.part2 + k.t0 * hd, hd,
-                                 false, R.gemm_ws, R.gemm_ws_bytes));
+    { int rc = layer_linear(c, rank, L.w2, act, k.tn, R.part2 + k.t0 * hd, hd, false); if (rc) return rc; }
     prof_end(R, &ev);
     return 0;
 }
@@ -1373,6 +1412,20 @@ int pplhip_op_linear_swiglu(void* stream, const void* x, const void* w, const vo
                             int32_t N, int32_t K, void* y) {
     return op_rc(launch_linear((hipStream_t)stream, (const uint16_t*)x, w, (const uint16_t*)scale, wq_bit, group, M, N, K, y, N / 2,
                                false, nullptr, 0, true));
+}
+
+int pplhip_op_quant_act(void* stream, const void* x, int64_t M, int32_t K, void* q, float* sx) {
+    return op_rc(launch_quant_act((hipStream_t)stream, (const uint16_t*)x, M, K, K, (int8_t*)q, K, sx));
+}
+
+int pplhip_op_quant_weight(void* stream, const void* w, int32_t N, int32_t K, void* q, void* scale) {
+    return op_rc(launch_quant_weight((hipStream_t)stream, (const uint16_t*)w, N, K, (int8_t*)q, K, (uint16_t*)scale));
+}
+
+int pplhip_op_linear_i8(void* stream, const void* xq, const float* sx, const void* w, const void* scale, int64_t M, int32_t N, int32_t K,
+                        void* y, int32_t out_fp32, int32_t swiglu) {
+    return op_rc(launch_linear_i8((hipStream_t)stream, (const int8_t*)xq, sx, (const int8_t*)w, (const uint16_t*)scale, M, N, K, y,
+                                  swiglu ? N / 2 : N, out_fp32 != 0, swiglu != 0));
 }
 
 int pplhip_op_silu_mul(void* stream, const void* gate_up, int64_t T, int32_t inter, void* out) {

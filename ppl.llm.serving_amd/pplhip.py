@@ -34,7 +34,7 @@ class ModelDesc(C.Structure):
                 ("norm_eps", C.c_float), ("rope_theta", C.c_float), ("max_position", C.c_int32),
                 ("cache_quant_bit", C.c_int32), ("cache_quant_group", C.c_int32), ("cache_layout", C.c_int32),
                 ("cache_mode", C.c_int32), ("page_size", C.c_int32), ("weight_quant_bit", C.c_int32),
-                ("weight_quant_group", C.c_int32)]
+                ("weight_quant_group", C.c_int32), ("act_quant_bit", C.c_int32)]
 
 
 class Opts(C.Structure):
@@ -77,7 +77,8 @@ SYMBOLS = [
     "pplhip_kv_block_bytes", "pplhip_kv_capacity", "pplhip_kv_alloc", "pplhip_kv_ptrs", "pplhip_kv_read",
     "pplhip_kv_write", "pplhip_kv_fill_synthetic", "pplhip_set_inputs", "pplhip_run", "pplhip_logits", "pplhip_copy_logits", "pplhip_sync",
     "pplhip_sample", "pplhip_penalty", "pplhip_profile_reset", "pplhip_profile_get", "pplhip_mem_info",
-    "pplhip_op_embedding", "pplhip_op_rmsnorm", "pplhip_op_linear", "pplhip_op_linear_swiglu", "pplhip_op_silu_mul", "pplhip_op_rope_kv_write",
+    "pplhip_op_embedding", "pplhip_op_rmsnorm", "pplhip_op_linear", "pplhip_op_linear_swiglu", "pplhip_op_quant_act", "pplhip_op_quant_weight",
+    "pplhip_op_linear_i8", "pplhip_op_silu_mul", "pplhip_op_rope_kv_write",
     "pplhip_op_attention", "pplhip_build_rope_table",
 ]
 
@@ -126,6 +127,9 @@ def lib():
         L.pplhip_op_rmsnorm.argtypes = [vp, vp, vp, vp, f32, i64, i32, vp, vp]
         L.pplhip_op_linear.argtypes = [vp, vp, vp, vp, i32, i32, i64, i32, i32, vp, i32]
         L.pplhip_op_linear_swiglu.argtypes = [vp, vp, vp, vp, i32, i32, i64, i32, i32, vp]
+        L.pplhip_op_quant_act.argtypes = [vp, vp, i64, i32, vp, vp]
+        L.pplhip_op_quant_weight.argtypes = [vp, vp, i32, i32, vp, vp]
+        L.pplhip_op_linear_i8.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, vp, i32, i32]
         L.pplhip_op_silu_mul.argtypes = [vp, vp, i64, i32, vp]
         L.pplhip_op_rope_kv_write.argtypes = [vp, vp, vp, C.POINTER(KvView), vp, vp, vp, i64, i64, i64, i32]
         L.pplhip_op_attention.argtypes = [vp, vp, C.POINTER(KvView), vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, i32,
@@ -138,7 +142,7 @@ def lib():
 def make_desc(**kw):
     d = ModelDesc()
     defaults = dict(norm_eps=1e-5, rope_theta=10000.0, max_position=4096, cache_quant_bit=0, cache_quant_group=1,
-                    cache_layout=3, cache_mode=0, page_size=0, weight_quant_bit=0, weight_quant_group=128)
+                    cache_layout=3, cache_mode=0, page_size=0, weight_quant_bit=0, weight_quant_group=128, act_quant_bit=0)
     defaults.update(kw)
     for k, v in defaults.items():
         setattr(d, k, v)

@@ -137,9 +137,17 @@ RetCode HipResourceManager::Init(const ModelConfig& mc, const ResourceConfig& rc
         LOG(ERROR) << "tensor_parallel_size must be a power of two";
         return RC_INVALID_VALUE;
     }
-    if (rc.engine_config.quant_method != "none" && !rc.engine_config.quant_method.empty()) {
-        LOG(ERROR) << "unknown/unsupported --quant-method option: " << rc.engine_config.quant_method
+    // the reference's two modes (src/backends/cuda/resource_manager.cc:49-56): "none" and "online_i8i8" (W8A8: int8 weights
+    // quantised per output row at load time unless the slices already hold int8, int8 activations per token at run time)
+    const std::string& qm = rc.engine_config.quant_method;
+    const bool online_i8i8 = qm == "online_i8i8";
+    if (!online_i8i8 && qm != "none" && !qm.empty()) {
+        LOG(ERROR) << "unknown/unsupported --quant-method option: " << qm
                    << " (weight-only quantisation is a property of the exported slices: params.json weight_quant_bit)";
+        return RC_UNSUPPORTED;
+    }
+    if (online_i8i8 && mc.weight_quant_bit == 4) {
+        LOG(ERROR) << "--quant-method online_i8i8 needs fp16 or int8 (per-channel) slices; these are W4A16";
         return RC_UNSUPPORTED;
     }
     pplhip_model_desc d;
@@ -158,8 +166,9 @@ RetCode HipResourceManager::Init(const ModelConfig& mc, const ResourceConfig& rc
     d.cache_layout = mc.cache_layout;
     d.cache_mode = mc.cache_mode;
     d.page_size = mc.page_size;
-    d.weight_quant_bit = mc.weight_quant_bit;
+    d.weight_quant_bit = online_i8i8 ? 8 : mc.weight_quant_bit;
     d.weight_quant_group = mc.weight_quant_group;
+    d.act_quant_bit = online_i8i8 ? 8 : 0;
 
     pplhip_opts o;
     memset(&o, 0, sizeof(o));

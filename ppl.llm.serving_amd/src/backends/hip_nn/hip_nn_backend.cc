@@ -212,6 +212,12 @@ RetCode Backend::Init(const ModelConfig& mc, const ResourceConfig& rc, const Ext
     d.cache_quant_bit = mc.cache_quant_bit; d.cache_quant_group = mc.cache_quant_group; d.cache_layout = mc.cache_layout;
     d.cache_mode = mc.cache_mode; d.page_size = mc.page_size;
     d.weight_quant_bit = ex.weight_quant_bit; d.weight_quant_group = ex.weight_quant_group;
+    if (rc.engine_config.quant_method == "online_i8i8") {  // the reference's W8A8 mode (src/backends/cuda/resource_manager.cc:51-52)
+        if (d.weight_quant_bit == 4) return ppl::common::RC_UNSUPPORTED;
+        d.weight_quant_bit = 8; d.act_quant_bit = 8;
+    } else if (rc.engine_config.quant_method != "none" && !rc.engine_config.quant_method.empty()) {
+        return ppl::common::RC_UNSUPPORTED;
+    }
     pplhip_opts o;
     memset(&o, 0, sizeof(o));
     o.n_local_ranks = I.tp; o.world_size = I.tp;

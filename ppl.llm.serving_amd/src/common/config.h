@@ -36,7 +36,7 @@ struct ResourceConfig final {
         bool disable_decoding_inf_gqa = false;        // accepted, ignored
         int32_t configure_decoding_attn_split_k = 1;  // 0 off / 1 heuristic / 2 always
         int32_t specify_decoding_attn_tpb = 0;        // 0 heuristic / 256 / 512
-        std::string quant_method = "none";            // ("online_i8i8" = W8A8 is not on the north-star path)
+        std::string quant_method = "none";            // or "online_i8i8" (W8A8)
     };
     EngineConfig engine_config;
 };

@@ -29,7 +29,7 @@ def test_struct_layouts_match_oracle():
     """pplhip_model_desc / pplhip_step and the oracle's ref_model_desc / ref_step are the same bytes."""
     from oracle import ref
     m = load_pplhip()
-    assert ctypes.sizeof(m.ModelDesc) == ctypes.sizeof(ref.ModelDesc) == 64
+    assert ctypes.sizeof(m.ModelDesc) == ctypes.sizeof(ref.ModelDesc) == 68
     assert ctypes.sizeof(m.Step) == ctypes.sizeof(ref.Step)
     assert [f[0] for f in m.ModelDesc._fields_] == [f[0] for f in ref.ModelDesc._fields_]
     assert [f[0] for f in m.Step._fields_] == [f[0] for f in ref.Step._fields_]

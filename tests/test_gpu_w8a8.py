@@ -1,0 +1,139 @@
+"""online_i8i8 (W8A8; the reference's second --quant-method, src/backends/cuda/resource_manager.cc:51-52) against the CPU
+oracle (oracle/llama_ref.c: ref_quant_act_rows / ref_quant_weight_rows / linear_fwd_a8).  The quantisers and the int8 GEMM
+are integer work: bit-exact, including the fp16 result (the two fp32 multiplies of the epilogue run in the oracle's order).
+Only the fused SwiGLU epilogue (device __expf) and whole-model logits (fp32 accumulation order upstream of a quantiser)
+carry a tolerance."""
+import numpy as np
+import pytest
+
+from oracle import ref
+from tests.conftest import load_pplhip
+from tests.test_gpu_model import check_steps, generate_both
+from tests.test_gpu_ops import ck, close_f16, dev, f16, _drop_device_tensors  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.mark.parametrize("M,K", [(1, 128), (37, 4096), (5, 1376), (64, 11008), (3, 8)])
+def test_quant_act_bit_exact(M, K):
+    m = load_pplhip()
+    rng = np.random.default_rng(M + K)
+    x = f16(rng.standard_normal((M, K)) * rng.uniform(0.01, 30, size=(M, 1)))
+    if M > 2:
+        x[2] = 0  # an all-zero token row: scale 0, bytes 0
+    xs = x.astype(np.float32)
+    wq, wsx = np.empty((M, K), np.int8), np.empty(M, np.float32)
+    ref.lib().ref_quant_act_rows(xs.ctypes.data, M, K, wq.ctypes.data, wsx.ctypes.data)
+    q = torch.empty((M, K), dtype=torch.int8, device="cuda")
+    sx = torch.empty(M, dtype=torch.float32, device="cuda")
+    ck(m.lib().pplhip_op_quant_act(None, dev(x).data_ptr(), M, K, q.data_ptr(), sx.data_ptr()))
+    assert (q.cpu().numpy() == wq).all()
+    assert (sx.cpu().numpy() == wsx).all()
+
+
+@pytest.mark.parametrize("N,K", [(48, 256), (300, 4096), (16, 1376)])
+def test_quant_weight_bit_exact(N, K):
+    m = load_pplhip()
+    rng = np.random.default_rng(N + K)
+    w = f16(rng.standard_normal((N, K)) * rng.uniform(0.001, 0.2, size=(N, 1)))
+    w[1] = 0
+    wq, ws = np.empty((N, K), np.int8), np.empty(N, np.float16)
+    ref.lib().ref_quant_weight_rows(w.ctypes.data, N, K, wq.ctypes.data, ws.ctypes.data)
+    q = torch.empty((N, K), dtype=torch.int8, device="cuda")
+    s = torch.empty(N, dtype=torch.float16, device="cuda")
+    ck(m.lib().pplhip_op_quant_weight(None, dev(w).data_ptr(), N, K, q.data_ptr(), s.data_ptr()))
+    assert (q.cpu().numpy() == wq).all()
+    assert (s.cpu().numpy().view(np.uint16) == ws.view(np.uint16)).all()
+
+
+def quantised_inputs(M, N, K, seed):
+    rng = np.random.default_rng(seed)
+    x = f16(rng.standard_normal((M, K)) * 1.5)
+    xs = x.astype(np.float32)
+    xq, sx = np.empty((M, K), np.int8), np.empty(M, np.float32)
+    ref.lib().ref_quant_act_rows(xs.ctypes.data, M, K, xq.ctypes.data, sx.ctypes.data)
+    w = rng.integers(-127, 128, size=(N, K)).astype(np.int8)
+    scale = f16(0.0005 * (0.5 + rng.random(N)))
+    return xs, xq, sx, w, scale
+
+
+# skinny (M <= 16), generic (K % 128 != 0 or M <= 32), tile kernel (ragged M and N edges), the configurations' layer shapes
+@pytest.mark.parametrize("M,N,K", [(1, 256, 4096), (7, 4096, 4096), (16, 12288, 4096), (16, 22016, 1376), (33, 512, 1376),
+                                   (24, 512, 256), (33, 512, 256), (200, 1000, 512), (129, 132, 128), (1024, 4096, 4096),
+                                   (1024, 4096, 11008), (1024, 5120, 6912), (300, 1280, 8192)])
+def test_linear_i8_bit_exact(M, N, K):
+    m = load_pplhip()
+    xs, xq, sx, w, scale = quantised_inputs(M, N, K, M + N + K)
+    dxq, dsx, dw, ds = dev(xq), dev(sx), dev(w), dev(scale)
+    for out_fp32 in (0, 1):
+        want = np.empty((M, N), dtype=np.float32)
+        ref.lib().ref_linear_i8_raw(xs.ctypes.data, w.ctypes.data, scale.ctypes.data, M, N, K, want.ctypes.data, out_fp32)
+        y = torch.empty((M, N), dtype=torch.float32 if out_fp32 else torch.float16, device="cuda")
+        ck(m.lib().pplhip_op_linear_i8(None, dxq.data_ptr(), dsx.data_ptr(), dw.data_ptr(), ds.data_ptr(), M, N, K, y.data_ptr(),
+                                       out_fp32, 0))
+        got = y.float().cpu().numpy()
+        assert (got == want).all(), (np.abs(got - want).max(), int((got != want).sum()))
+
+
+@pytest.mark.parametrize("M,inter,K", [(5, 688, 512), (200, 1376, 512), (40, 176, 256)])
+def test_linear_i8_swiglu(M, inter, K):
+    m = load_pplhip()
+    N = 2 * inter
+    xs, xq, sx, w, scale = quantised_inputs(M, N, K, M + inter)
+    gu = np.empty((M, N), dtype=np.float32)
+    ref.lib().ref_linear_i8_raw(xs.ctypes.data, w.ctypes.data, scale.ctypes.data, M, N, K, gu.ctypes.data, 0)
+    want = np.empty((M, inter), dtype=np.float32)
+    ref.lib().ref_silu_mul(gu.ctypes.data, M, inter, want.ctypes.data)
+    perm = np.empty(N, dtype=np.int64)
+    perm[0::2], perm[1::2] = np.arange(inter), inter + np.arange(inter)
+    y = torch.empty((M, inter), dtype=torch.float16, device="cuda")
+    ck(m.lib().pplhip_op_linear_i8(None, dev(xq).data_ptr(), dev(sx).data_ptr(), dev(np.ascontiguousarray(w[perm])).data_ptr(),
+                                   dev(np.ascontiguousarray(scale[perm])).data_ptr(), M, N, K, y.data_ptr(), 0, 1))
+    close_f16(y.cpu().numpy(), want, rel=1.5e-3, abs_=1e-5)   # gate and up are bit-exact; silu uses the device's __expf
+
+
+@pytest.mark.parametrize("kvq,mode,inter,heads,kv_heads", [(0, 0, 512, 4, 4), (8, 1, 176, 4, 2), (0, 1, 1376, 8, 8)])
+def test_synthetic_model_w8a8(kvq, mode, inter, heads, kv_heads):
+    """the whole decoder in online_i8i8 mode: packed ragged prefill + decode steps against the oracle."""
+    m = load_pplhip()
+    desc = ref.make_desc(hidden_dim=256, intermediate_dim=inter, num_layers=2, num_heads=heads, num_kv_heads=kv_heads,
+                         vocab_size=1024, max_position=512, cache_quant_bit=kvq, cache_quant_group=8 if kvq else 1,
+                         cache_layout=3, cache_mode=mode, page_size=16 if mode else 0, weight_quant_bit=8, act_quant_bit=8)
+    rm = ref.RefModel(desc)
+    rm.init_synthetic(4321)
+    ctx = m.Context(m.copy_desc(desc), max_running_batch=16, max_tokens_per_step=256)
+    ctx.init_synthetic(0, 4321)
+    rm.kv_alloc(1024)
+    ctx.kv_alloc(0, 1024)
+    rng = np.random.RandomState(11)
+    prompts = [rng.randint(3, 1024, size=n) for n in (70, 3, 129, 1, 16)]
+    # a quantiser is discontinuous: an activation that differs from the oracle's by one fp16 rounding can move one int8
+    # by one step, which is worth ~1/127 of that element -- noise of the same class as the int8 KV cache (k = 2)
+    check_steps(generate_both(m, ctx, [rm], desc, prompts, 4, 1024), k=3 if kv_heads != heads else 2)
+    ctx.close()
+
+
+def test_online_weight_quantisation_on_upload():
+    """online_i8i8's "online": fp16 matrices handed to pplhip_rank_set_tensor are quantised per output row on the device
+    (the kernel test_quant_weight_bit_exact pins; w13 rows are interleaved first), the oracle does the same in ref_set_tensor:
+    a model loaded from an fp16 container agrees like one loaded from int8 tensors."""
+    m = load_pplhip()
+    desc = ref.make_desc(hidden_dim=256, intermediate_dim=176, num_layers=1, num_heads=4, num_kv_heads=4, vocab_size=512,
+                         max_position=256, weight_quant_bit=8, act_quant_bit=8)
+    fp = ref.make_desc(hidden_dim=256, intermediate_dim=176, num_layers=1, num_heads=4, num_kv_heads=4, vocab_size=512,
+                       max_position=256)
+    src = ref.RefModel(fp)
+    src.init_synthetic(5)
+    rm = ref.RefModel(desc)
+    ctx = m.Context(m.copy_desc(desc), max_running_batch=8, max_tokens_per_step=64)
+    for name in ref.tensor_names(fp):
+        t = src.get_tensor(name, np.uint8)
+        rm.set_tensor(name, t)
+        ctx.set_tensor(0, name, t)
+    rm.kv_alloc(256)
+    ctx.kv_alloc(0, 256)
+    rng = np.random.RandomState(5)
+    prompts = [rng.randint(3, 512, size=n) for n in (20, 1, 37)]
+    check_steps(generate_both(m, ctx, [rm], desc, prompts, 3, 256), k=2)
+    ctx.close()

@@ -1,0 +1,89 @@
+"""The oracle's online_i8i8 (W8A8) restatement against independent numpy arithmetic (no GPU).  The reference only names the
+mode (src/backends/cuda/resource_manager.cc:51-52) and leaves the arithmetic to ppl.nn, which is not in the tree: these
+numerics are this build's specification, parity with the reference unpinned."""
+import importlib.util
+import os
+
+import numpy as np
+
+from oracle import ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _exporter():
+    spec = importlib.util.spec_from_file_location("export_hf_llama", os.path.join(ROOT, "ppl.llm.serving_amd", "tools", "export_hf_llama.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_weight_rows_equal_the_exporters_w8():
+    rng = np.random.default_rng(0)
+    w = (rng.standard_normal((64, 384)) * rng.uniform(0.001, 0.3, size=(64, 1))).astype(np.float16)
+    w[3] = 0
+    q, s = np.empty((64, 384), np.int8), np.empty(64, np.float16)
+    ref.lib().ref_quant_weight_rows(w.ctypes.data, 64, 384, q.ctypes.data, s.ctypes.data)
+    eq, es = _exporter().quant_w8(w)
+    assert (q == eq).all() and (s.view(np.uint16) == es.view(np.uint16)).all()
+
+
+def test_act_rows_and_linear_against_numpy():
+    rng = np.random.default_rng(1)
+    M, N, K = 9, 40, 272
+    x = (rng.standard_normal((M, K)) * 3).astype(np.float16).astype(np.float32)
+    x[4] = 0
+    q, sx = np.empty((M, K), np.int8), np.empty(M, np.float32)
+    ref.lib().ref_quant_act_rows(x.ctypes.data, M, K, q.ctypes.data, sx.ctypes.data)
+    amax = np.abs(x).max(1)
+    inv = np.where(amax > 0, np.float32(127.0) / np.where(amax > 0, amax, 1), 0).astype(np.float32)
+    want_q = np.clip(np.rint(x * inv[:, None]), -127, 127).astype(np.int8)
+    assert (q == want_q).all()
+    assert (sx == (amax / np.float32(127.0)).astype(np.float32)).all()
+    assert (np.abs(q).max(1)[amax > 0] == 127).all() and (q[4] == 0).all()
+
+    w = rng.integers(-127, 128, size=(N, K)).astype(np.int8)
+    scale = (0.001 * (0.5 + rng.random(N))).astype(np.float16)
+    for out_fp32 in (0, 1):
+        y = np.empty((M, N), np.float32)
+        ref.lib().ref_linear_i8_raw(x.ctypes.data, w.ctypes.data, scale.ctypes.data, M, N, K, y.ctypes.data, out_fp32)
+        acc = q.astype(np.int32) @ w.astype(np.int32).T
+        want = (acc.astype(np.float32) * sx[:, None]) * scale.astype(np.float32)[None, :]
+        if not out_fp32:
+            want = want.astype(np.float16).astype(np.float32)
+        assert (y == want).all()
+
+
+def test_w8a8_model_tracks_the_w8a16_model():
+    """same int8 weights, activations additionally quantised: logits move by the quantisation noise only."""
+    kw = dict(hidden_dim=128, intermediate_dim=256, num_layers=2, num_heads=4, num_kv_heads=4, vocab_size=256, max_position=64,
+              weight_quant_bit=8)
+    outs = []
+    for a8 in (0, 8):
+        d = ref.make_desc(act_quant_bit=a8, **kw)
+        rm = ref.RefModel(d)
+        rm.init_synthetic(9)
+        rm.kv_alloc(64)
+        tok = np.arange(3, 23)
+        st = ref.make_step(tok, [0, 12, 20], [0, 0], [0, 32], 0)
+        outs.append(ref.forward([rm], st))
+    a, b = outs
+    assert np.abs(a - b).max() < 0.05 * np.abs(a).max() and not (a == b).all()
+
+
+def test_online_quantisation_in_set_tensor():
+    """an fp16 matrix handed to an int8 linear is quantised on the way in (online_i8i8), anything else must match in size"""
+    d = ref.make_desc(hidden_dim=64, intermediate_dim=128, num_layers=1, num_heads=2, num_kv_heads=2, vocab_size=64, max_position=32,
+                      weight_quant_bit=8, act_quant_bit=8)
+    rm = ref.RefModel(d)
+    rng = np.random.default_rng(2)
+    w = (rng.standard_normal((64, 64)) * 0.05).astype(np.float16)
+    rm.set_tensor("layers.0.attention.wo.weight", w)
+    q, s = _exporter().quant_w8(w)
+    assert (rm.get_tensor("layers.0.attention.wo.weight", np.int8).reshape(64, 64) == q).all()
+    assert (rm.get_tensor("layers.0.attention.wo.scale", np.uint16) == s.view(np.uint16)).all()
+    try:
+        rm.set_tensor("layers.0.attention.wo.weight", w[:10])
+        raise AssertionError("size mismatch accepted")
+    except RuntimeError:
+        pass
