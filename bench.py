@@ -294,8 +294,14 @@ def main():
         # one process per GPU: exchange the IPC handles of the exchange regions, then the collective self-test decides
         # between the direct kernels and RCCL (the same decision on every rank)
         handles = [None] * world
-        dist.all_gather_object(handles, ctx.comm_export(0))
-        ctx.comm_connect(handles)
+        try:
+            mine = ctx.comm_export(0)
+        except RuntimeError as e:   # no IPC handle for the exchange region on this rank: every rank then stays on RCCL
+            print(f"[bench] rank {rank}: {e}", file=sys.stderr)
+            mine = None
+        dist.all_gather_object(handles, mine)
+        if all(h is not None for h in handles):
+            ctx.comm_connect(handles)
     comm_mode = {0: "none", 1: "rccl", 2: "direct xGMI kernels (two-shot, all links)"}[ctx.comm_mode()]
     ctx.init_synthetic(0, 1234)
     kv_tokens = B * total_len if args.cache_mode == 0 else B * ((total_len + 15) // 16) * 16

@@ -276,7 +276,9 @@ int p2p_unavailable(pplhip_ctx* c, int rank, const std::string& why) {
 // Runs both collectives four times on changing patterns on every local rank (all ranks of the group do this at the same time,
 // in this process or in others) and compares with the exact answer.  Every rank then learns whether ALL ranks passed
 // (one RCCL all-reduce when a communicator exists); only then comm_mode becomes 2.
-int p2p_selftest(pplhip_ctx* c) {
+// `local_failure`: this process could not even map its peers -- it skips the kernels but still takes part in the agreement, so that
+// the other processes (whose self-test kernels give up waiting for it after the bounded spin) do not wait in the all-reduce forever.
+int p2p_selftest(pplhip_ctx* c, const std::string* local_failure = nullptr) {
     const int n = (int)c->ranks.size(), tp = c->tp, hd = c->d.hidden_dim;
     const int64_t cnt = std::min<int64_t>((int64_t)1 << 20, c->ranks[0].cap_T * (int64_t)hd) / 4 * 4;
     // the gather test: every rank's [grows, gcols] fp32 block -> [grows, gcols * tp]
@@ -285,8 +287,8 @@ int p2p_selftest(pplhip_ctx* c) {
     const char* e = getenv("PPLHIP_P2P_SELFTEST_MS");
     const uint64_t ticks = (uint64_t)(e ? std::max(1, atoi(e)) : 10000) * 100000ull;
     auto pat = [](int64_t i, int g, int round) { return p2p_pattern_value(i, g, round); };
-    bool ok = true;
-    std::string why;
+    bool ok = local_failure == nullptr;
+    std::string why = local_failure ? *local_failure : std::string();
     std::vector<uint16_t> hbuf(cnt);
     std::vector<float> gbuf(gcnt), gall;
     for (int round = 0; round < 4 && ok; ++round) {
@@ -711,7 +713,11 @@ int pplhip_comm_connect(pplhip_ctx* c, const void* all_handles) {
                 Rank& Q = c->ranks[g - base];
                 if (Q.device != R.device) {
                     hipError_t e = hipDeviceEnablePeerAccess(Q.device, 0);
-                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); return p2p_unavailable(c, r, std::string("peer access: ") + hipGetErrorString(e)); }
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                        (void)hipGetLastError();
+                        const std::string why = std::string("peer access: ") + hipGetErrorString(e);
+                        return p2p_selftest(c, &why);
+                    }
                     (void)hipGetLastError();
                 }
                 R.peers.base[g] = Q.xbase;
@@ -721,7 +727,11 @@ int pplhip_comm_connect(pplhip_ctx* c, const void* all_handles) {
             memcpy(&h, (const char*)all_handles + (size_t)g * PPLHIP_IPC_HANDLE_BYTES, sizeof(h));
             void* ptr = nullptr;
             hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
-            if (e != hipSuccess) { (void)hipGetLastError(); return p2p_unavailable(c, r, std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e)); }
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                const std::string why = std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e);
+                return p2p_selftest(c, &why);
+            }
             R.peers.base[g] = (char*)ptr;
             R.peer_ipc[g] = true;
         }
