@@ -36,7 +36,9 @@ tokens per second, time to first token, batch size 1024, sequence length 1024, t
 TEXTS = ["Hello, my name is", "The president of the United States is", " leading space", "trailing space ", "two  spaces   three",
          "", " ", "\n", "tab\tseparated\tvalues", "naïve café déjà vu", "数学は美しい", "emoji 🙂 and 𝔘𝔫𝔦𝔠𝔬𝔡𝔢", "price: $1,234.56 (approx.)",
          "line one\nline two\r\nline three", "ÀÈÌÒÙ àèìòù ÄËÏÖÜ", "x" * 40, "a b c d e f g", "Zażółć gęślą jaźń", "مرحبا بالعالم",
-         "mixed 日本語 and English 123", "▁already escaped", "snake_case and camelCase and kebab-case"]
+         "mixed 日本語 and English 123", "▁already escaped", "snake_case and camelCase and kebab-case",
+         # literal U+2581 in the input: the trailing clean-up strips the space SYMBOL, the merge rule only real spaces
+         "ends with the symbol▁", "▁", "▁▁ x ▁ ▁", "a ▁ b", "  ▁  both ▁▁", "δ▁"]
 
 
 def train(name, **kw):

@@ -181,34 +181,34 @@ int SentencePieceModel::PieceToId(const std::string& piece) const {
     return it == piece_to_id_.end() ? unk_id_ : it->second;
 }
 
-// normalizer.cc with the identity rule: optional whitespace clean-up, dummy prefix, ' ' -> U+2581
+// normalizer.cc (Normalizer::Normalize) with the identity character map: leading spaces dropped and runs of spaces merged when
+// remove_extra_whitespaces, dummy prefix, ' ' -> U+2581, and -- as the library does it -- the trailing clean-up strips the SPACE
+// SYMBOL from the normalised string, so a literal U+2581 at the end of the input goes too (and takes the dummy prefix with it
+// when nothing else is left).
 std::string SentencePieceModel::Normalize(const char* text, size_t len) const {
-    std::string s(text, len);
-    if (remove_extra_whitespaces_) {
-        std::string t;
-        size_t b = 0, e = s.size();
-        while (b < e && s[b] == ' ') ++b;
-        while (e > b && s[e - 1] == ' ') --e;
-        bool prev_space = false;
-        for (size_t i = b; i < e; ++i) {
-            if (s[i] == ' ') {
-                if (!prev_space) t += ' ';
-                prev_space = true;
-            } else {
-                t += s[i];
-                prev_space = false;
-            }
-        }
-        s.swap(t);
-    }
-    if (s.empty()) return s;
+    size_t b = 0;
+    if (remove_extra_whitespaces_)
+        while (b < len && text[b] == ' ') ++b;
     std::string out;
-    out.reserve(s.size() + 8);
-    if (add_dummy_prefix_) out += escape_whitespaces_ ? kSpaceSymbol : " ";
-    for (char c : s) {
-        if (c == ' ' && escape_whitespaces_) out += kSpaceSymbol;
-        else out += c;
+    if (b == len) return out;
+    out.reserve(len - b + 8);
+    const std::string space = escape_whitespaces_ ? std::string(kSpaceSymbol) : std::string(" ");
+    if (add_dummy_prefix_) out += space;
+    bool is_prev_space = remove_extra_whitespaces_;
+    for (size_t i = b; i < len; ++i) {
+        const char c = text[i];
+        if (c == ' ') {
+            if (is_prev_space) continue;
+            out += space;
+            is_prev_space = remove_extra_whitespaces_;
+        } else {
+            out += c;
+            is_prev_space = false;
+        }
     }
+    if (remove_extra_whitespaces_)
+        while (out.size() >= space.size() && out.compare(out.size() - space.size(), space.size(), space) == 0)
+            out.resize(out.size() - space.size());
     return out;
 }
 
