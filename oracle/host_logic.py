@@ -152,12 +152,29 @@ def simulate(sc):
     idx, slots, pages, pc = IndexManager(N), IndexManager(max_batch), PageManager(N, P), PrefixCacheManager()
     queue = [dict(r) for r in sc["requests"]]
     stash = None
-    rows = []            # running requests (dicts), row order
-    mi = dict(decoding_batches=0, max_pages=0, start_pos=[], cache_indices=[], page_list=[], batch_slots=[])
-    finished = []        # finished_tasks queue (ids)
     responses, failed, steps = {}, {}, []
-    running_batch, cool, changed, loop_step, runs = 0, 0, True, 0, 0
+    runs = 0
+    # GeneratorThreadFunc (:342-366): Generate() returns when nothing is running (:657-660) and is entered again while the
+    # scheduler still holds requests -- with fresh locals (running_batch, cool-down count, loop_step, ModelInput, :574-590).
+    # NB the stale running_batch of :628 (the previous step's batch, finished rows included) makes a request that fits an idle
+    # generator wait for exactly that re-entry.
+    while queue or stash is not None:
+        rows = []            # running requests (dicts), row order
+        mi = dict(decoding_batches=0, max_pages=0, start_pos=[], cache_indices=[], page_list=[], batch_slots=[])
+        finished = []        # finished_tasks queue (ids)
+        running_batch, cool, changed, loop_step = 0, 0, True, 0
+        stash, runs = _generate(locals())
+    return steps, responses, failed
 
+
+def _generate(E):
+    """one call of LLMGenerator::Generate on the state `E` built by simulate(); returns (stash, runs)"""
+    (mode, P, vocab, max_batch, max_in, max_out, max_total, max_step, max_cool, prefix, max_prefill, penalty, gstop, fail_at_run,
+     cancel, idx, slots, pages, pc, queue, stash, responses, failed, steps, runs, rows, mi, finished, running_batch, cool, changed,
+     loop_step) = [E[k] for k in ("mode", "P", "vocab", "max_batch", "max_in", "max_out", "max_total", "max_step", "max_cool", "prefix",
+                                  "max_prefill", "penalty", "gstop", "fail_at_run", "cancel", "idx", "slots", "pages", "pc", "queue",
+                                  "stash", "responses", "failed", "steps", "runs", "rows", "mi", "finished", "running_batch", "cool",
+                                  "changed", "loop_step")]
     while True:
         hit_flag = False
         tot = running_batch                                  # :628-631
@@ -304,8 +321,19 @@ def simulate(sc):
             finished.append(cid)
         # ---- Execute; failure path :681-688
         if fail_at_run >= 0 and runs == fail_at_run:
+            runs += 1
             for t in rows:
                 failed[t["tid"]] = 1                           # RC_OTHER_ERROR from LLMEngine::Execute
+            # ReleaseResource :368-385 -- every page of a running request goes back (cached prefix pages included) and the
+            # prefix cache is dropped whole
+            for i, t in enumerate(rows):
+                if mode == 0:
+                    idx.release(t["cache_index"], t["total_len"] - 1)
+                else:
+                    pages.release(t["pages"])
+                if penalty:
+                    slots.release(mi["batch_slots"][i], 1)
+            pc.reset()
             break
         runs += 1
         changed = False
@@ -369,4 +397,4 @@ def simulate(sc):
             else:
                 mi["max_pages"] = max([len(t["pages"]) for t in rows], default=0)
         loop_step += 1
-    return steps, responses, failed
+    return stash, runs

@@ -78,7 +78,7 @@ def run_cpp(trace_bin, sc):
         json.dump(sc, f)
         path = f.name
     try:
-        out = subprocess.check_output([trace_bin, path], stderr=subprocess.DEVNULL, timeout=120).decode().strip().split("\n")
+        out = subprocess.check_output([trace_bin, path], stderr=subprocess.DEVNULL, timeout=int(os.environ.get("SCHED_TRACE_TIMEOUT", "120"))).decode().strip().split("\n")
     finally:
         os.unlink(path)
     lines = [json.loads(l) for l in out]
@@ -250,7 +250,9 @@ def compare_with_reference(ref_trace_bin, sc, skip_upload_flag_at=()):
     assert len(rsteps) == len(steps), (len(rsteps), len(steps))
     mode = sc["model"].get("cache_mode", 0)
     for a, b in zip(rsteps, steps):
-        for k in ("step", "decoding_batches", "max_seq_len", "max_kv_len", "token_inputs", "seq_starts", "kv_starts", "start_pos", "prefix_hit"):
+        # (the driver's "step" counts Execute calls; the generator's own loop_step restarts with every Generate() call and is not
+        # visible to a backend)
+        for k in ("decoding_batches", "max_seq_len", "max_kv_len", "token_inputs", "seq_starts", "kv_starts", "start_pos", "prefix_hit"):
             assert a[k] == b[k], (b["step"], k, a[k], b[k])
         if mode == 0:
             assert a["cache_indices"] == b["cache_indices"], b["step"]
@@ -360,3 +362,33 @@ def test_cpp_text_request_streams_pieces_and_buffers_split_characters(trace_bin)
     pieces = by_text["a b c d e f g"]
     want_tail = [(" " + d) if (p.startswith("▁") and d and d[0] != " ") else d for p, d in zip(pieces["pieces"][:2], pieces["per_token"][:2])]
     assert texts == ["", "", "世"] + want_tail
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 5. Generate() re-entry and a fixed sample of the differential fuzz (oracle/sched_fuzz.py; 1000 scenarios agreed three ways)
+# ---------------------------------------------------------------------------------------------------------------
+def test_idle_generator_is_reentered_for_the_stashed_request(trace_bin):
+    """llm_generator.cc:628 charges the PREVIOUS step's batch size (finished rows included) against max_tokens_per_step, so a
+    prompt that exactly fills the budget is refused right after a step that finished everything; Generate() then returns
+    (:657-660) and GeneratorThreadFunc (:342-366) enters it again with fresh locals, where the request is admitted."""
+    sc = {"model": {"cache_mode": 0, "vocab_size": 997}, "generator": {"max_running_batch": 4, "max_tokens_per_step": 12, "max_prefill_batch": 2},
+          "kv_cache_max_tokens": 64,
+          "requests": [{"id": 0, "tokens": list(range(10, 20)), "generation_length": 1}, {"id": 1, "tokens": [30, 31], "generation_length": 1},
+                       {"id": 2, "tokens": list(range(40, 52)), "generation_length": 1}]}
+    steps, responses, failed = compare(trace_bin, sc)
+    assert [s["step"] for s in steps] == [0, 0] and [len(s["token_inputs"]) for s in steps] == [12, 12]
+    assert sorted(responses) == [0, 1, 2] and not failed
+
+
+def test_scheduler_fuzz_sample(trace_bin):
+    from oracle.sched_fuzz import scenario
+    rng = np.random.RandomState(5)
+    for _ in range(40):
+        compare(trace_bin, scenario(rng))
+
+
+def test_reference_sources_scheduler_fuzz_sample(ref_trace_bin):
+    from oracle.sched_fuzz import scenario
+    rng = np.random.RandomState(5)
+    for _ in range(40):
+        compare_with_reference(ref_trace_bin, scenario(rng))
