@@ -108,6 +108,27 @@ def ragged_kv_lengths(B, seed=1234, cap=1024):
     return p + (rng.rand(B) * o).astype(np.int64)
 
 
+def i8i8_leg(args):
+    """the same decode steps in the reference's OTHER int8 mode, --quant-method online_i8i8 (W8A8: src/backends/cuda/resource_manager.cc:51-52)
+    -- a secondary number beside the W8A16 headline BASELINE.json's configs name; its own process, after this one released the GPU"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--act-quant", "8", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--kv-len", str(args.kv_len), "--kv-quant", str(args.kv_quant), "--cache-mode", str(args.cache_mode), "--no-cpu-baseline",
+           "--no-serving-leg", "--no-i8i8-leg", "--ragged-steps", "0"]
+    try:
+        out = subprocess.run(cmd, capture_output=True, timeout=600)
+        lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+        if out.returncode != 0 or not lines:
+            return {"error": f"rc {out.returncode}: {out.stderr.decode()[-300:]}"}
+        r = json.loads(lines[-1])
+        return {"what": "same workload, int8 activations x int8 weights (per-token / per-output-row scales), int32 accumulate",
+                "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+                "gemm_and_quantisers_ms_per_step": r["breakdown_ms_per_step"]["gemm"],
+                "attn_decode_ms_per_step": r["breakdown_ms_per_step"]["attn_decode"], "prefill_step_ms": r.get("prefill_step_ms")}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def serving_leg(model_kw, args):
     """BASELINE's metric is decode tokens/s + p50 TTFT: the samples_1024-shaped token-in/out load through the C++ generator
     + engine + hip backend (tools/offline_inference --workload samples1024, the in-process counterpart of the reference's
@@ -230,6 +251,8 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="debug only: override the layer count (result is then INVALID)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serving-leg", action="store_true", help="skip the samples_1024-shaped serving run (TTFT)")
+    ap.add_argument("--no-i8i8-leg", action="store_true",
+                    help="skip the secondary run of the same decode step in the reference's other int8 mode (--quant-method online_i8i8)")
     ap.add_argument("--ragged-steps", type=int, default=4, help="decode steps at a samples_1024-shaped ragged kv_len batch (0: skip)")
     ap.add_argument("--tpb", type=int, default=0)
     ap.add_argument("--prefill-sample", type=int, default=1, help="also time one 8192-token prefill step (TTFT proxy)")
@@ -464,6 +487,9 @@ def main():
                 sv = {"error": repr(e)}
             res["serving"] = sv
             res["ttft_p50_ms"] = sv.get("ttft_p50_ms")
+        if (world == 1 and not args.no_i8i8_leg and not args.layers and not args.emulate_tp and args.act_quant == 0 and args.weight_quant == 8
+                and args.model == "llama2-7b" and B == 1024):
+            res["online_i8i8"] = i8i8_leg(args)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(mk, args.kv_len)
