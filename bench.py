@@ -114,7 +114,7 @@ def i8i8_leg(args):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--act-quant", "8", "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--kv-len", str(args.kv_len), "--kv-quant", str(args.kv_quant), "--cache-mode", str(args.cache_mode), "--no-cpu-baseline",
-           "--no-serving-leg", "--no-i8i8-leg", "--ragged-steps", "0"]
+           "--no-serving-leg", "--no-i8i8-leg", "--ragged-steps", "0", "--breakdown"]
     try:
         out = subprocess.run(cmd, capture_output=True, timeout=600)
         lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
@@ -251,6 +251,8 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="debug only: override the layer count (result is then INVALID)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serving-leg", action="store_true", help="skip the samples_1024-shaped serving run (TTFT)")
+    ap.add_argument("--breakdown", action="store_true",
+                    help="also time the GEMM launches (events around every kernel class: costs the step ~3 %%; default: decode attention only)")
     ap.add_argument("--no-i8i8-leg", action="store_true",
                     help="skip the secondary run of the same decode step in the reference's other int8 mode (--quant-method online_i8i8)")
     ap.add_argument("--ragged-steps", type=int, default=4, help="decode steps at a samples_1024-shaped ragged kv_len batch (0: skip)")
@@ -312,7 +314,7 @@ def main():
     # collectives) on a one-GPU box; needs PPLHIP_COMM=p2p because RCCL refuses two ranks on one device
     dev = 0 if os.environ.get("PPLHIP_BENCH_ONE_DEVICE") else local_rank
     ctx = P.Context(desc, max_running_batch=B, max_tokens_per_step=max(8192, B), n_local_ranks=1, world_size=tp,
-                    rank_base=rank, device_ids=[dev], unique_id=uid, profiling=True, tpb=args.tpb)
+                    rank_base=rank, device_ids=[dev], unique_id=uid, profiling=1 if args.breakdown else 2, tpb=args.tpb)
     if world > 1 and os.environ.get("PPLHIP_COMM") != "rccl":
         # one process per GPU: exchange the IPC handles of the exchange regions, then the collective self-test decides
         # between the direct kernels and RCCL (the same decision on every rank)
@@ -469,8 +471,9 @@ def main():
                          "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "launches": n_attn, "avg_launch_ms": round(ms_attn / max(n_attn, 1), 4),
                          "algorithmic_bytes_per_launch": int(bytes_total / max(n_attn, 1))},
-            "breakdown_ms_per_step": {"attn_decode": round(ms_attn / K, 3), "gemm": round(ms_gemm / K, 3),
-                                      "run_total_gpu": round(ms_run / K, 3)},
+            "breakdown_ms_per_step": {"attn_decode": round(ms_attn / K, 3), "gemm": round(ms_gemm / K, 3) if args.breakdown else None,
+                                      "run_total_gpu": round(ms_run / K, 3),
+                                      "note": None if args.breakdown else "GEMM launches not bracketed (--breakdown does, at ~3 % of the step)"},
         }
         res.update(extra)
         if ragged is not None:

@@ -82,7 +82,8 @@ typedef struct pplhip_opts {
     int32_t enable_penalty;    /* --enable-penalty */
     int32_t decoding_attn_split_k; /* --configure-decoding-attn-split-k: 0 off, 1 heuristic, 2 always */
     int32_t decoding_attn_tpb;     /* --specify-decoding-attn-tpb: 0 heuristic, 256, 512 */
-    int32_t enable_profiling;  /* record HIP events around the dominant kernels (see pplhip_profile_*) */
+    int32_t enable_profiling;  /* record HIP events around the dominant kernels (see pplhip_profile_*): 1 = every class,
+                                  2 = decode attention and the whole run only (an event record is a barrier packet) */
 } pplhip_opts;
 
 #define PPLHIP_UNIQUE_ID_BYTES 128

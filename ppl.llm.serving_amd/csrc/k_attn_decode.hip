@@ -16,6 +16,7 @@
 //   8-channel partial dot product, not each element.
 // Numerics: fp32 everywhere, output rounded to fp16 once.  Oracle: ref_attention (oracle/llama_ref.c).
 #include <stdlib.h>
+#include <hip/hip_ext.h>
 #include "k_attn_decode_dev.h"
 
 namespace pplhip {
@@ -55,11 +56,18 @@ size_t attn_decode_workspace_bytes(int64_t nb, int H, int D, int split) {
 template <int QBIT, int D>
 static hipError_t launch_decode_t(hipStream_t s, const uint16_t* qkv, const KvAddr& kv, const int64_t* seq_starts,
                                   const int64_t* start_pos, const int64_t* cache_indices, int64_t max_pages, int64_t nb,
-                                  int H, int Hkv, int split, int threads, float* workspace, uint16_t* out) {
+                                  int H, int Hkv, int split, int threads, float* workspace, uint16_t* out, hipEvent_t t0,
+                                  hipEvent_t t1) {
     const int nw = threads / 64;
     const size_t lds = (size_t)nw * (D + 2) * sizeof(float);
-    hipLaunchKernelGGL((attn_decode_kernel<QBIT, D>), dim3(H, (unsigned)nb, split), dim3(threads), lds, s, qkv, kv,
-                       seq_starts, start_pos, cache_indices, max_pages, H, Hkv, split, workspace, out);
+    // t0 / t1: start and stop timestamps taken from the kernel's own dispatch packet -- no extra barrier packets on the stream
+    // (an hipEventRecord pair around the launch costs ~10 us of GPU time)
+    if (t0 && t1)
+        hipExtLaunchKernelGGL((attn_decode_kernel<QBIT, D>), dim3(H, (unsigned)nb, split), dim3(threads), lds, s, t0, t1, 0, qkv, kv,
+                              seq_starts, start_pos, cache_indices, max_pages, H, Hkv, split, workspace, out);
+    else
+        hipLaunchKernelGGL((attn_decode_kernel<QBIT, D>), dim3(H, (unsigned)nb, split), dim3(threads), lds, s, qkv, kv,
+                           seq_starts, start_pos, cache_indices, max_pages, H, Hkv, split, workspace, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (split > 1) {
@@ -73,7 +81,7 @@ static hipError_t launch_decode_t(hipStream_t s, const uint16_t* qkv, const KvAd
 hipError_t launch_attn_decode(hipStream_t s, const uint16_t* qkv, const KvAddr& kv, int quant_bit,
                               const int64_t* seq_starts, const int64_t* start_pos, const int64_t* cache_indices,
                               int64_t max_pages, int64_t nb, int H, int Hkv, int D, int64_t max_kv_len, int split,
-                              int threads, float* workspace, uint16_t* out) {
+                              int threads, float* workspace, uint16_t* out, hipEvent_t t0, hipEvent_t t1) {
     if (nb == 0) return hipSuccess;
     static const int forced_tpb = getenv("PPLHIP_ATTN_TPB") ? atoi(getenv("PPLHIP_ATTN_TPB")) : 0;  // tuning only
     if (forced_tpb) threads = forced_tpb;
@@ -84,8 +92,10 @@ hipError_t launch_attn_decode(hipStream_t s, const uint16_t* qkv, const KvAddr& 
     static const bool no_gqa = getenv("PPLHIP_ATTN_NOGQA") != nullptr;
     const int grp = H / Hkv;
     if (grp >= 4 && grp <= 16 && !no_gqa) {
+        if (t0 && t1) (void)hipEventRecord(t0, s);
         hipError_t e = launch_attn_decode_gqa(s, qkv, kv, quant_bit, seq_starts, start_pos, cache_indices, max_pages, nb, H,
                                               Hkv, D, split, workspace, out);
+        if (t0 && t1) (void)hipEventRecord(t1, s);
         if (e != hipSuccess || split == 1) return e;
         const dim3 rg((unsigned)(nb * H)), rb(D < 64 ? 64 : D);
         if (D == 128) hipLaunchKernelGGL((attn_decode_reduce_kernel<128>), rg, rb, 0, s, workspace, split, out);
@@ -96,7 +106,7 @@ hipError_t launch_attn_decode(hipStream_t s, const uint16_t* qkv, const KvAddr& 
 #define DEC_CASE(QB, DD)                                                                                            \
     if (quant_bit == QB && D == DD)                                                                                 \
         return launch_decode_t<QB, DD>(s, qkv, kv, seq_starts, start_pos, cache_indices, max_pages, nb, H, Hkv,     \
-                                       split, threads, workspace, out);
+                                       split, threads, workspace, out, t0, t1);
     DEC_CASE(8, 128) DEC_CASE(0, 128) DEC_CASE(8, 64) DEC_CASE(0, 64) DEC_CASE(8, 32) DEC_CASE(0, 32)
 #undef DEC_CASE
     return hipErrorInvalidValue;

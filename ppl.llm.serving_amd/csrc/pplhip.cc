@@ -236,6 +236,9 @@ KvAddr make_kv_addr(const pplhip_model_desc& d, int Hkv, int D, uint64_t tokens,
 void prof_begin(pplhip_ctx* c, Rank& R, int cls, ProfEvent* ev) {
     ev->cls = -1;
     if (!c->o.enable_profiling) return;
+    // 2 = light: only the decode-attention launches (through hipExtLaunchKernel's start / stop events) and the whole run.  An event record is a barrier packet on the
+    // stream: the full set (10 per layer) costs a batch-1024 decode step 1.3 ms of 43.9 (profiles/probes/prof_overhead.py)
+    if (c->o.enable_profiling == 2 && cls != PPLHIP_PROF_RUN) return;   // (decode attention: timed through its own launch)
     std::pair<hipEvent_t, hipEvent_t> p;
     if (!R.prof_free.empty()) { p = R.prof_free.back(); R.prof_free.pop_back(); }
     else { hipEventCreate(&p.first); hipEventCreate(&p.second); }
@@ -1108,11 +1111,24 @@ static int layer_attention_part(pplhip_ctx* c, int rank, int l, const Chunk& k, 
     // prefill requests: absolute request range
     const int64_t ci_stride = d.cache_mode == 1 ? R.max_pages : 1;
     if (k.nd > 0) {
-        prof_begin(c, R, PPLHIP_PROF_ATTN_DECODE, &ev);
-        HIPCK(c, rank, launch_attn_decode(s, R.qkv, kv, d.cache_quant_bit, R.d_seq + k.b0, R.d_sp + k.b0, R.d_ci + k.b0 * ci_stride,
-                                          R.max_pages, k.nd, H, Hkv, D, R.max_kv_len, split, threads, R.attn_ws,
-                                          R.att + k.b0 * (int64_t)H * D));
-        prof_end(R, &ev);
+        if (c->o.enable_profiling == 2) {
+            // light profiling: the launch carries its own start / stop events (timestamps of the dispatch packet, no barrier
+            // packets on the stream; with split-K the reduce kernel is not included)
+            std::pair<hipEvent_t, hipEvent_t> p;
+            if (!R.prof_free.empty()) { p = R.prof_free.back(); R.prof_free.pop_back(); }
+            else { hipEventCreate(&p.first); hipEventCreate(&p.second); }
+            ev.cls = PPLHIP_PROF_ATTN_DECODE; ev.a = p.first; ev.b = p.second;
+            HIPCK(c, rank, launch_attn_decode(s, R.qkv, kv, d.cache_quant_bit, R.d_seq + k.b0, R.d_sp + k.b0, R.d_ci + k.b0 * ci_stride,
+                                              R.max_pages, k.nd, H, Hkv, D, R.max_kv_len, split, threads, R.attn_ws,
+                                              R.att + k.b0 * (int64_t)H * D, ev.a, ev.b));
+            R.prof.push_back(ev);
+        } else {
+            prof_begin(c, R, PPLHIP_PROF_ATTN_DECODE, &ev);
+            HIPCK(c, rank, launch_attn_decode(s, R.qkv, kv, d.cache_quant_bit, R.d_seq + k.b0, R.d_sp + k.b0, R.d_ci + k.b0 * ci_stride,
+                                              R.max_pages, k.nd, H, Hkv, D, R.max_kv_len, split, threads, R.attn_ws,
+                                              R.att + k.b0 * (int64_t)H * D));
+            prof_end(R, &ev);
+        }
     }
     if (k.bn > k.nd) {
         prof_begin(c, R, PPLHIP_PROF_ATTN_PREFILL, &ev);

@@ -13,7 +13,9 @@ LABEL=${1:-r02}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py 2>$R/gpurun_out/r02_bench.err > $R/gpurun_out/r02_bench.json
-LEAN="--no-cpu-baseline --no-serving-leg --prefill-sample 0"
+# the same steps with every kernel class bracketed by events (GEMM ms/step; costs the step ~3 %)
+python $R/bench.py --breakdown --no-cpu-baseline --no-serving-leg --no-i8i8-leg --ragged-steps 0 2>/dev/null > $R/gpurun_out/r02_bench_breakdown.json
+LEAN="--no-cpu-baseline --no-serving-leg --no-i8i8-leg --prefill-sample 0"
 rm -rf /tmp/prof_stats
 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -- python $R/bench.py $LEAN > /tmp/prof_stats.log 2>&1
 db=$(find /tmp/prof_stats -name "*.db" | head -1)
