@@ -103,3 +103,44 @@ def test_invalid_page_lists_are_rejected():
     ctx.run(0)
     assert np.isfinite(ctx.copy_logits(1)).all()
     ctx.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_decode_steps_replayed_as_hip_graphs_are_bit_identical(monkeypatch, mode):
+    """PPLHIP_DECODE_GRAPH=1: the second decode step of a shape is captured, later ones are replayed -- token ids, positions,
+    cache slots and page lists come from the step buffer, so the replay must give exactly the eager logits, also across a page
+    boundary (the page-table width is part of the shape key) and after the batch shrank and grew back."""
+    m = load_pplhip()
+
+    def run(graph):
+        monkeypatch.setenv("PPLHIP_DECODE_GRAPH", "1" if graph else "0")
+        desc, ctx, _ = make(m, mode=mode, batch=6, tokens=64, max_position=128, kv_tokens=6 * 48)
+        rng = np.random.RandomState(4)
+        lens = np.array([5, 9, 3, 7, 2, 6])
+        ci = (np.arange(6, dtype=np.int64) * 48) if mode == 0 else np.arange(6 * 6, dtype=np.int64).reshape(6, 6)
+        mp = 6 if mode else 0
+        tok = rng.randint(3, 320, size=int(lens.sum()))
+        ctx.set_inputs(0, m.make_step(tok, np.concatenate([[0], np.cumsum(lens)]), np.zeros(6, dtype=np.int64), ci, 0, max_pages=mp))
+        ctx.run(0)
+        out = [ctx.copy_logits(6)]
+        sp = lens.copy()
+        rows = np.arange(6)
+        for i in range(14):
+            if i == 6:
+                rows = np.array([0, 2, 3, 5])          # two requests leave ...
+            if i == 10:
+                rows = np.arange(6)                    # ... and the same shape comes back
+            nxt = rng.randint(3, 320, size=len(rows))
+            st = m.make_step(nxt, np.arange(len(rows) + 1), sp[rows], ci[rows], len(rows), max_pages=mp,
+                             req_list_changed=int(i in (0, 6, 10)))
+            ctx.set_inputs(0, st)
+            ctx.run(0)
+            out.append(ctx.copy_logits(len(rows)))
+            sp[rows] += 1
+        ctx.close()
+        return out
+
+    eager, graph = run(False), run(True)
+    assert len(eager) == len(graph)
+    for a, b in zip(eager, graph):
+        assert (a == b).all()
