@@ -110,7 +110,7 @@ def test_synthetic_model_w8a8(kvq, mode, inter, heads, kv_heads):
     prompts = [rng.randint(3, 1024, size=n) for n in (70, 3, 129, 1, 16)]
     # a quantiser is discontinuous: an activation that differs from the oracle's by one fp16 rounding can move one int8
     # by one step, which is worth ~1/127 of that element -- noise of the same class as the int8 KV cache (k = 2)
-    check_steps(generate_both(m, ctx, [rm], desc, prompts, 4, 1024), k=3 if kv_heads != heads else 2)
+    check_steps(generate_both(m, ctx, [rm], desc, prompts, 4, 1024), k=2)   # observed (r02): <= 1.2e-3
     ctx.close()
 
 
