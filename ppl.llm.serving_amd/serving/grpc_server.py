@@ -39,18 +39,20 @@ class Config(C.Structure):
                 ("max_input_tokens_per_request", C.c_int32), ("max_output_tokens_per_request", C.c_int32),
                 ("max_total_tokens_per_request", C.c_int32), ("max_prefill_batch", C.c_int32), ("max_cooldown_request", C.c_int32),
                 ("enable_prefix_cache", C.c_int32), ("enable_penalty", C.c_int32), ("stop_tokens", C.POINTER(C.c_int32)),
-                ("n_stop_tokens", C.c_int32)]
+                ("n_stop_tokens", C.c_int32), ("tokenizer_path", C.c_char_p), ("tokenizer_type", C.c_char_p),
+                ("model_type", C.c_char_p), ("quant_method", C.c_char_p)]
 
 
 class CRequest(C.Structure):
     _fields_ = [("id", C.c_uint64), ("tokens", C.POINTER(C.c_int32)), ("n_tokens", C.c_int32), ("temperature", C.c_float),
                 ("top_p", C.c_float), ("top_k", C.c_int32), ("repetition_penalty", C.c_float), ("presence_penalty", C.c_float),
-                ("frequency_penalty", C.c_float), ("generation_length", C.c_int32), ("early_stopping", C.c_int32)]
+                ("frequency_penalty", C.c_float), ("generation_length", C.c_int32), ("early_stopping", C.c_int32),
+                ("prompt", C.c_char_p), ("n_prompt", C.c_int32)]
 
 
 class CResponse(C.Structure):
     _fields_ = [("id", C.c_uint64), ("token", C.c_int32), ("logprob", C.c_float), ("status", C.c_int32),
-                ("finish_reason", C.c_int32), ("is_special", C.c_int32), ("reserved", C.c_int32)]
+                ("finish_reason", C.c_int32), ("is_special", C.c_int32), ("text_len", C.c_int32), ("text_off", C.c_int64)]
 
 
 def load_lib():
@@ -60,6 +62,7 @@ def load_lib():
     L.pplsrv_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
     L.pplsrv_submit.argtypes = [C.c_void_p, C.POINTER(CRequest), C.c_int32]
     L.pplsrv_poll.argtypes = [C.c_void_p, C.POINTER(CResponse), C.c_int32, C.c_int32]
+    L.pplsrv_poll_text.argtypes = [C.c_void_p, C.POINTER(CResponse), C.c_int32, C.c_int32, C.c_char_p, C.c_int64]
     L.pplsrv_cancel.argtypes = [C.c_void_p, C.c_uint64]
     L.pplsrv_kv_cache_max_tokens.argtypes = [C.c_void_p]
     L.pplsrv_kv_cache_max_tokens.restype = C.c_uint64
@@ -80,26 +83,11 @@ def parse_request(pb):
                 generation_length=int(sp.max_new_tokens), early_stopping=0 if sp.ignore_eos_token else 1)
 
 
-class Tokenizer:
-    """sentencepiece text path (src/tokenizer/tokenizer_impl_sp.h:31-74): BOS is prepended on encode; a decoded piece gets
-    its leading space back when the sentencepiece piece starts with U+2581 (:53-59)."""
-
-    def __init__(self, path):
-        import sentencepiece as spm
-        self.sp = spm.SentencePieceProcessor(model_file=path)
-
-    def encode(self, text):
-        return [self.sp.bos_id()] + self.sp.encode(text) if self.sp.bos_id() >= 0 else self.sp.encode(text)
-
-    def decode_one(self, token):
-        piece = self.sp.id_to_piece(int(token))
-        text = self.sp.decode([int(token)])
-        return (" " + text) if piece.startswith("▁") and not text.startswith(" ") else text
-
-
 class Serving:
-    def __init__(self, lib, handle, tokenizer=None):
-        self.lib, self.h, self.tok = lib, handle, tokenizer
+    def __init__(self, lib, handle, has_tokenizer=False):
+        # text requests are tokenised and detokenised INSIDE the C++ generator (src/tokenizer, LLMGenerator::Process and
+        # DecodeAndSend with its U+FFFD buffering), like the reference's server; this shell only moves bytes
+        self.lib, self.h, self.has_tok = lib, handle, has_tokenizer
         self.loop = None
         self.uuid_seq = 0                     # mapped ids: unique across calls (grpc_server.cc:176-178)
         self.routes = {}                      # mapped id -> (asyncio.Queue of the call, client id, text mode)
@@ -115,8 +103,10 @@ class Serving:
 
     def _poll(self):
         buf = (CResponse * 4096)()
+        tcap = 1 << 20
+        tbuf = C.create_string_buffer(tcap)
         while not self.stop:
-            n = self.lib.pplsrv_poll(self.h, buf, 4096, 50)
+            n = self.lib.pplsrv_poll_text(self.h, buf, 4096, 50, tbuf, tcap)
             if n <= 0:
                 continue
             per_call = {}
@@ -129,8 +119,9 @@ class Serving:
                     q, orig_id, text = route
                     if r.status != P.PROCESSING:
                         del self.routes[r.id]
+                    piece = tbuf.raw[r.text_off:r.text_off + r.text_len].decode("utf-8", errors="replace") if (text and r.text_off >= 0) else ""
                     per_call.setdefault(id(q), (q, []))[1].append((orig_id, r.token, r.logprob, r.status, r.finish_reason,
-                                                                   r.is_special, text))
+                                                                   r.is_special, text, piece))
             for q, items in per_call.values():
                 self.loop.call_soon_threadsafe(q.put_nowait, items)
 
@@ -155,15 +146,21 @@ class Serving:
         mapped = []
         for i, pb in enumerate(request.req):
             text = bool(pb.prompt)
-            if text and self.tok is None:
+            if text and not self.has_tok:
                 failed.append(pb.id)          # no tokenizer configured: the text path cannot be served
                 continue
-            tokens = self.tok.encode(pb.prompt) if text else list(pb.tokens.ids)
-            arr = (C.c_int32 * max(len(tokens), 1))(*tokens)
-            keep.append(arr)
             kw = parse_request(pb)
             c = creqs[len(mapped)]
-            c.id, c.tokens, c.n_tokens = base + i, arr, len(tokens)
+            c.id = base + i
+            if text:
+                raw = pb.prompt.encode("utf-8")
+                keep.append(raw)
+                c.tokens, c.n_tokens, c.prompt, c.n_prompt = None, 0, raw, len(raw)
+            else:
+                tokens = list(pb.tokens.ids)
+                arr = (C.c_int32 * max(len(tokens), 1))(*tokens)
+                keep.append(arr)
+                c.tokens, c.n_tokens, c.prompt, c.n_prompt = arr, len(tokens), None, 0
             for k, v in kw.items():
                 setattr(c, k, v)
             mapped.append((base + i, pb.id, text))
@@ -189,14 +186,14 @@ class Serving:
             while pending > 0:
                 items = await q.get()
                 out = P.BatchedResponse()
-                for orig_id, token, logprob, status, reason, special, text in items:
+                for orig_id, token, logprob, status, reason, special, text, piece in items:
                     r = out.rsp.add()
                     r.status, r.id = status, orig_id
                     if status == P.FAILED:
                         pending -= 1
                         continue
                     if text:
-                        r.generated = self.tok.decode_one(token)
+                        r.generated = piece
                     else:
                         r.tokens.ids.append(token & 0xFFFFFFFF)
                     r.detail.logprobs, r.detail.is_special, r.detail.finish_reason = logprob, bool(special), reason
@@ -223,7 +220,9 @@ def make_config(a):
                  max_output_tokens_per_request=a.max_output_tokens_per_request,
                  max_total_tokens_per_request=a.max_total_tokens_per_request, max_prefill_batch=a.max_prefill_batch,
                  max_cooldown_request=a.max_cooldown_request, enable_prefix_cache=int(a.enable_prefix_cache),
-                 enable_penalty=int(a.enable_penalty), stop_tokens=arr, n_stop_tokens=len(stop))
+                 enable_penalty=int(a.enable_penalty), stop_tokens=arr, n_stop_tokens=len(stop),
+                 tokenizer_path=(a.tokenizer_path or "").encode(), tokenizer_type=(a.tokenizer_type or "sentencepiece").encode(),
+                 model_type=(a.model_type or "llama").encode(), quant_method=(a.quant_method or "none").encode())
     cfg._keep = arr
     return cfg
 
@@ -245,6 +244,9 @@ def add_flags(ap):
     ap.add_argument("--enable-penalty", action="store_true")
     ap.add_argument("--stop-tokens", default="")
     ap.add_argument("--tokenizer-path", default="", help="sentencepiece model; without it only the token-in/token-out path is served")
+    ap.add_argument("--tokenizer-type", default="sentencepiece")
+    ap.add_argument("--model-type", default="llama")
+    ap.add_argument("--quant-method", default="none", help="none | online_i8i8 (tools/llm_server.cc:62)")
     ap.add_argument("--synthetic-weights", action="store_true")
     ap.add_argument("--synthetic-seed", type=int, default=1234)
     ap.add_argument("--kv-cache-max-tokens", type=int, default=0)
@@ -258,7 +260,7 @@ async def serve(a, ready=None):
     rc = lib.pplsrv_create(C.byref(make_config(a)), C.byref(h))
     if rc != 0:
         raise RuntimeError(f"pplsrv_create failed: RetCode {-rc}")
-    srv = Serving(lib, h, Tokenizer(a.tokenizer_path) if a.tokenizer_path else None)
+    srv = Serving(lib, h, bool(a.tokenizer_path))
     srv.start(asyncio.get_running_loop())
     server = grpc.aio.server(options=[("grpc.max_receive_message_length", 64 << 20), ("grpc.max_send_message_length", 64 << 20)])
     handler = grpc.method_handlers_generic_handler(P.SERVICE, {

@@ -1,6 +1,7 @@
 #include "capi/serving_c.h"
 
 #include <chrono>
+#include <cstring>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -11,6 +12,7 @@
 #include "common/request.h"
 #include "common/resource.h"
 #include "generator/llm_generator.h"
+#include "tokenizer/tokenizer_factory.h"
 
 using namespace ppl::llm;
 using ppl::common::RetCode;
@@ -32,7 +34,9 @@ public:
             o.status = r.finish_flag == FinishFlag::NOT_FINISHED ? PPLSRV_PROCESSING : PPLSRV_FINISHED;
             o.finish_reason = r.finish_flag == FinishFlag::EOS_TOKEN ? PPLSRV_REASON_EOS
                             : r.finish_flag == FinishFlag::STOP_SEQUENCE ? PPLSRV_REASON_STOP : PPLSRV_REASON_LENGTH;
+            o.text_off = -1;
             q_.push_back(o);
+            text_.push_back(r.generated);
         }
         cv_.notify_all();
     }
@@ -41,16 +45,30 @@ public:
         pplsrv_response o{};
         o.id = id;
         o.status = PPLSRV_FAILED;
+        o.text_off = -1;
         q_.push_back(o);
+        text_.emplace_back();
         cv_.notify_all();
     }
-    int Poll(pplsrv_response* out, int max, int timeout_ms) {
+    int Poll(pplsrv_response* out, int max, int timeout_ms, char* text_buf, int64_t text_cap) {
         std::unique_lock<std::mutex> lk(mu_);
         if (q_.empty() && timeout_ms > 0) cv_.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return !q_.empty(); });
         int n = 0;
+        int64_t used = 0;
         while (n < max && !q_.empty()) {
-            out[n++] = q_.front();
+            const std::string& t = text_.front();
+            // a response whose text does not fit any more stays queued for the next call (unless it could never fit)
+            if (text_buf && !t.empty() && used + (int64_t)t.size() > text_cap && n > 0) break;
+            out[n] = q_.front();
+            if (text_buf && !t.empty() && used + (int64_t)t.size() <= text_cap) {
+                memcpy(text_buf + used, t.data(), t.size());
+                out[n].text_off = used;
+                out[n].text_len = (int32_t)t.size();
+                used += (int64_t)t.size();
+            }
+            ++n;
             q_.pop_front();
+            text_.pop_front();
         }
         return n;
     }
@@ -59,6 +77,7 @@ private:
     std::mutex mu_;
     std::condition_variable cv_;
     std::deque<pplsrv_response> q_;
+    std::deque<std::string> text_;  // Response::generated of q_[i]
 };
 
 }  // namespace
@@ -68,6 +87,7 @@ struct pplsrv {
     hip::HipResourceManager resource_manager;
     Resource resource;
     QueueConnection conn;
+    std::unique_ptr<Tokenizer> tokenizer;
     std::unique_ptr<LLMGenerator> generator;
 };
 
@@ -91,6 +111,7 @@ int pplsrv_create(const pplsrv_config* cfg, pplsrv** out) {
     rc.synthetic_seed = cfg->synthetic_seed;
     rc.kv_cache_max_tokens_override = cfg->kv_cache_max_tokens;
     rc.engine_config.configure_decoding_attn_split_k = 1;
+    if (cfg->quant_method && cfg->quant_method[0]) rc.engine_config.quant_method = cfg->quant_method;
     gc.top_p = 0.f;
     gc.top_k = 1;
     gc.enable_penalty = rc.enable_penalty;
@@ -109,6 +130,13 @@ int pplsrv_create(const pplsrv_config* cfg, pplsrv** out) {
     RetCode st = s->resource_manager.Init(mc, rc);
     if (st != ppl::common::RC_SUCCESS) return -(int)st;
     s->resource_manager.FillResource(&s->resource);
+    if (cfg->tokenizer_path && cfg->tokenizer_path[0]) {  // tools/llm_server.cc: the tokenizer belongs to the Resource
+        s->tokenizer.reset(TokenizerFactory::Create(cfg->model_type && cfg->model_type[0] ? cfg->model_type : "llama",
+                                                    cfg->tokenizer_type && cfg->tokenizer_type[0] ? cfg->tokenizer_type : "sentencepiece",
+                                                    cfg->tokenizer_path, ""));
+        if (!s->tokenizer) return -(int)ppl::common::RC_INVALID_VALUE;
+        s->resource.tokenizer = s->tokenizer.get();
+    }
     s->generator.reset(new LLMGenerator(s->resource, gc, mc, &s->conn));
     st = s->generator->Init();
     if (st != ppl::common::RC_SUCCESS) return -(int)st;
@@ -130,9 +158,18 @@ int pplsrv_submit(pplsrv* s, const pplsrv_request* reqs, int32_t n) {
         r->frequency_penalty = q.frequency_penalty;
         r->generation_length = q.generation_length;
         r->early_stopping = q.early_stopping != 0;
-        r->is_token_in_out = true;
-        r->token_ids = std::make_shared<std::vector<int>>(q.tokens, q.tokens + (q.n_tokens > 0 ? q.n_tokens : 0));
-        r->stop_tokens = std::make_shared<std::unordered_set<int>>();  // grpc_server.cc:225 builds an empty set as well
+        if (!q.tokens && q.prompt) {
+            // text request (grpc_server.cc:218-252): LLMGenerator::Process tokenises it and adds the EOS id to its stop tokens
+            if (!s->resource.tokenizer) {
+                s->conn.NotifyFailure(q.id, ppl::common::RC_INVALID_VALUE, "no tokenizer configured");
+                continue;
+            }
+            r->prompt.assign(q.prompt, q.n_prompt > 0 ? (size_t)q.n_prompt : 0);
+        } else {
+            r->is_token_in_out = true;
+            r->token_ids = std::make_shared<std::vector<int>>(q.tokens, q.tokens + (q.n_tokens > 0 ? q.n_tokens : 0));
+            r->stop_tokens = std::make_shared<std::unordered_set<int>>();  // grpc_server.cc:225 builds an empty set as well
+        }
         s->generator->Process(r);
     }
     return 0;
@@ -140,7 +177,12 @@ int pplsrv_submit(pplsrv* s, const pplsrv_request* reqs, int32_t n) {
 
 int pplsrv_poll(pplsrv* s, pplsrv_response* out, int32_t max, int32_t timeout_ms) {
     if (!s || !out || max <= 0) return 0;
-    return s->conn.Poll(out, max, timeout_ms);
+    return s->conn.Poll(out, max, timeout_ms, nullptr, 0);
+}
+
+int pplsrv_poll_text(pplsrv* s, pplsrv_response* out, int32_t max, int32_t timeout_ms, char* text_buf, int64_t text_buf_bytes) {
+    if (!s || !out || max <= 0) return 0;
+    return s->conn.Poll(out, max, timeout_ms, text_buf, text_buf ? text_buf_bytes : 0);
 }
 
 int pplsrv_cancel(pplsrv* s, uint64_t id) {

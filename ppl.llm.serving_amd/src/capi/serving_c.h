@@ -27,6 +27,11 @@ typedef struct pplsrv_config {
     int32_t enable_prefix_cache, enable_penalty;
     const int32_t* stop_tokens;    /* EOS-like tokens (GeneratorConfig::stop_tokens) */
     int32_t n_stop_tokens;
+    const char* tokenizer_path;    /* --tokenizer-path: text requests are tokenised / detokenised inside the generator (src/tokenizer);
+                                      NULL or "": token-in/token-out only, a text request fails */
+    const char* tokenizer_type;    /* --tokenizer-type, NULL = "sentencepiece" */
+    const char* model_type;        /* --model-type, NULL = "llama" (LlamaTokenizer: BOS first) */
+    const char* quant_method;      /* --quant-method: NULL / "none" / "online_i8i8" */
 } pplsrv_config;
 
 /* ParseRequest of grpc_server.cc:218-252 already applied by the caller */
@@ -39,6 +44,8 @@ typedef struct pplsrv_request {
     float repetition_penalty, presence_penalty, frequency_penalty;
     int32_t generation_length;
     int32_t early_stopping;
+    const char* prompt;            /* text request (proto Request.prompt) when tokens == NULL: n_prompt UTF-8 bytes */
+    int32_t n_prompt;
 } pplsrv_request;
 
 enum { PPLSRV_PROCESSING = 0, PPLSRV_FINISHED = 1, PPLSRV_FAILED = 2 };          /* proto Status */
@@ -51,13 +58,17 @@ typedef struct pplsrv_response {
     int32_t status;
     int32_t finish_reason;
     int32_t is_special;
-    int32_t reserved;
+    int32_t text_len;              /* text requests: bytes of this response's `generated` text ... */
+    int64_t text_off;              /* ... at this offset of the text buffer handed to pplsrv_poll_text (-1: none / did not fit) */
 } pplsrv_response;
 
 PPLSRV_API int pplsrv_create(const pplsrv_config* cfg, pplsrv** out);      /* 0 on success, a negated RetCode otherwise */
 PPLSRV_API int pplsrv_submit(pplsrv* s, const pplsrv_request* reqs, int32_t n);
 /* waits up to timeout_ms for at least one response, then returns up to `max` of them (0 on timeout) */
 PPLSRV_API int pplsrv_poll(pplsrv* s, pplsrv_response* out, int32_t max, int32_t timeout_ms);
+/* the same, plus the generated text of text requests (what DecodeAndSendTask, llm_generator.cc:58-112, put into Response::generated:
+ * possibly empty while a multi-byte character is still incomplete): copied back to back into text_buf */
+PPLSRV_API int pplsrv_poll_text(pplsrv* s, pplsrv_response* out, int32_t max, int32_t timeout_ms, char* text_buf, int64_t text_buf_bytes);
 PPLSRV_API int pplsrv_cancel(pplsrv* s, uint64_t id);                      /* client went away: LLMGenerator::ClearTask */
 PPLSRV_API uint64_t pplsrv_kv_cache_max_tokens(pplsrv* s);
 PPLSRV_API void pplsrv_destroy(pplsrv* s);

@@ -111,3 +111,82 @@ def test_load_generator_against_the_server(server):
                                   timeout=300).decode()
     res = json.loads(out.strip().splitlines()[-1])
     assert res["failed"] == 0 and res["requests"] == 24 and res["out_tps"] > 0 and res["ttft_ms"]["p50"] > 0
+
+
+# ---- text requests: tokenised and detokenised inside the C++ generator (src/tokenizer), like the reference's server -------------
+@pytest.fixture(scope="module")
+def text_server(golden_dir, tmp_path_factory):
+    port = free_port()
+    cfg = json.load(open(CFG))
+    cfg["vocab_size"] = 420                                   # = the fixture tokenizer's vocabulary: every generated id is a piece
+    params = str(tmp_path_factory.mktemp("textsrv") / "params.json")
+    json.dump(cfg, open(params, "w"))
+    proc = subprocess.Popen([sys.executable, os.path.join(PKG, "serving", "grpc_server.py"), "--model-param-path", params,
+                             "--synthetic-weights", "--synthetic-seed", "77", "--kv-cache-max-tokens", "2048", "--max-running-batch", "16",
+                             "--max-tokens-per-step", "256", "--host", "127.0.0.1", "--port", str(port),
+                             "--tokenizer-path", os.path.join(golden_dir, "spm_bpe.model")], stderr=subprocess.PIPE, text=True)
+    t0 = time.time()
+    line = ""
+    while time.time() - t0 < 120:
+        line = proc.stderr.readline()
+        if "listening" in line or proc.poll() is not None:
+            break
+    assert "listening" in line, f"server did not start: {line}"
+    yield f"127.0.0.1:{port}"
+    proc.terminate()
+    try:
+        proc.wait(timeout=20)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+
+
+def reference_stream(sp, toks):
+    """DecodeAndSendTask (src/generator/llm_generator.cc:58-112) + SentencePieceTokenizer::Decode (tokenizer_impl_sp.h:53-59),
+    restated with the sentencepiece module: one response text per generated token"""
+    out, flag, buf = [], 0, [0, 0, 0]
+    for t in toks:
+        s = sp.decode([int(t)])
+        if sp.id_to_piece(int(t)).startswith("▁") and s and s[0] != " ":
+            s = " " + s
+        if s == "�" and flag < 3:
+            buf[flag] = int(t)
+            flag += 1
+            s = ""
+            if flag == 3:
+                s = sp.decode(buf)
+                flag, buf = 0, [0, 0, 0]
+        out.append(s)
+    return out
+
+
+def test_text_requests_stream_what_the_reference_rule_gives(text_server, golden_dir):
+    spm = pytest.importorskip("sentencepiece")
+    sp = spm.SentencePieceProcessor(model_file=os.path.join(golden_dir, "spm_bpe.model"))
+    assert sp.get_piece_size() == 420
+    prompts = ["Hello, my name is", "The president of the United States is", "naïve café 数学 🙂"]
+    n_new = 24
+    with grpc.insecure_channel(text_server) as ch:
+        stub = ch.unary_stream(P.METHOD, request_serializer=P.BatchedRequest.SerializeToString,
+                               response_deserializer=P.BatchedResponse.FromString)
+        br = P.BatchedRequest()
+        for i, text in enumerate(prompts):
+            r = br.req.add()                                  # text request
+            r.id, r.prompt = i, text
+            r.stopping_parameters.max_new_tokens = n_new
+            r.stopping_parameters.ignore_eos_token = True
+            r = br.req.add()                                  # the same prompt as tokens: LlamaTokenizer = BOS + pieces
+            r.id = 100 + i
+            r.tokens.ids.extend([sp.bos_id()] + sp.encode(text))
+            r.stopping_parameters.max_new_tokens = n_new
+            r.stopping_parameters.ignore_eos_token = True
+        pieces, tokens = {}, {}
+        for batch in stub(br, timeout=120):
+            for rsp in batch.rsp:
+                assert rsp.status != P.FAILED
+                if rsp.id >= 100:
+                    tokens.setdefault(rsp.id - 100, []).extend(rsp.tokens.ids)
+                else:
+                    pieces.setdefault(rsp.id, []).append(rsp.generated)
+    for i in range(len(prompts)):
+        assert len(tokens[i]) == n_new and len(pieces[i]) == n_new
+        assert pieces[i] == reference_stream(sp, tokens[i]), (i, pieces[i], tokens[i])

@@ -56,18 +56,19 @@ def test_parse_request_defaults():
     assert kw["top_k"] == 1 and kw["top_p"] == 0.0
 
 
-def test_tokenizer_text_path(tmp_path):
-    """sentencepiece text path of the server: BOS first, and a decoded piece gets its leading space back when the piece
-    starts with U+2581 (src/tokenizer/tokenizer_impl_sp.h:53-59)"""
-    spm = pytest.importorskip("sentencepiece")
-    corpus = tmp_path / "corpus.txt"
-    corpus.write_text("\n".join(["the quick brown fox jumps over the lazy dog", "hello world this is a tokenizer test",
-                                 "the president of the united states", "the capital of france is paris"] * 20))
-    spm.SentencePieceTrainer.train(input=str(corpus), model_prefix=str(tmp_path / "tok"), vocab_size=64, model_type="bpe",
-                                   bos_id=1, eos_id=2, unk_id=0, minloglevel=2)
-    tok = gs.Tokenizer(str(tmp_path / "tok.model"))
-    ids = tok.encode("the quick fox")
-    assert ids[0] == 1 and len(ids) > 1
-    text = "".join(tok.decode_one(t) for t in ids[1:])
-    assert text.strip() == "the quick fox"
-    assert text.startswith(" ")          # the first word piece carries the U+2581 marker
+def test_ctypes_mirrors_of_the_serving_abi(tmp_path):
+    """Config / CRequest / CResponse of grpc_server.py are the structs of src/capi/serving_c.h: sizes and the offsets of the fields
+    added for the text path (tokenizer inside the C++ generator), taken from a C program compiled against the header"""
+    import ctypes
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "capi/serving_c.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(pplsrv_config), sizeof(pplsrv_request), '
+                   'sizeof(pplsrv_response), offsetof(pplsrv_config, tokenizer_path), offsetof(pplsrv_config, quant_method), '
+                   'offsetof(pplsrv_request, prompt), offsetof(pplsrv_response, text_off)); return 0; }\n')
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "ppl.llm.serving_amd", "src"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [ctypes.sizeof(gs.Config), ctypes.sizeof(gs.CRequest), ctypes.sizeof(gs.CResponse), gs.Config.tokenizer_path.offset,
+            gs.Config.quant_method.offset, gs.CRequest.prompt.offset, gs.CResponse.text_off.offset]
+    assert got == want
