@@ -1,6 +1,6 @@
-// Device side of the decode attention kernel (K8): configuration and the workgroup body attn_decode_body.  A header so that
-// the fused attention + GEMM launch (k_fused.hip) can run the same body as one of its block roles; k_attn_decode.hip wraps it
-// into the stand-alone kernel.  Design notes: k_attn_decode.hip.
+// Device side of the decode attention kernel (K8): configuration and the workgroup body attn_decode_body; k_attn_decode.hip
+// wraps it into the kernel (the body is a header so that probes can run it inside other launches).  Design notes:
+// k_attn_decode.hip.
 #pragma once
 #include "kernels.h"
 

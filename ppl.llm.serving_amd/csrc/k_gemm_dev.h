@@ -1,6 +1,5 @@
 // Device side of the tile GEMM (128 x 128 x 64, LDS-DMA ring): constants, epilogues, conversion helpers and the block body
-// gemm_dma_body.  A header so that the fused attention + GEMM launch (k_fused.hip) can run the same body as one of its block
-// roles; k_gemm.hip wraps it into the stand-alone kernel.
+// gemm_dma_body; k_gemm.hip wraps it into the kernels and k_gemm_i8.hip shares the helpers.
 #pragma once
 #include <type_traits>
 #include "kernels.h"
