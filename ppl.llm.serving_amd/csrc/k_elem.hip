@@ -25,8 +25,9 @@ template <int MAXC>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint4* x /* may alias residual_out */, const uint4* __restrict__ skip,
                                                       const uint4* __restrict__ w, float eps, int chunks, int hidden,
                                                       const int64_t* __restrict__ gather, uint4* __restrict__ out,
-                                                      uint4* residual_out) {
+                                                      uint4* residual_out, int8_t* __restrict__ qout, float* __restrict__ sx) {
     __shared__ float red[4];
+    __shared__ float redq[4];
     const int64_t r = blockIdx.x;
     const int64_t src = gather ? gather[r + 1] - 1 : r;
     float v[MAXC][8];
@@ -61,29 +62,69 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint4* x /* may alia
     __syncthreads();
     ss = red[0] + red[1] + red[2] + red[3];
     const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
+    if (!qout) {
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = threadIdx.x + i * 256;
+            if (c < chunks) {
+                float wf[8], o[8];
+                unpack8(wraw[i], wf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = v[i][j] * inv * wf[j];
+                out[r * chunks + c] = pack8(o);
+            }
+        }
+        return;
+    }
+    // online_i8i8: the normalised row goes straight to the next linear's int8 operand (k_gemm_i8.hip, quant_act_kernel's
+    // arithmetic on the fp16-rounded values: sx = max|y| / 127, q = clamp(rint(y * (127 / max|y|))))
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const int c = threadIdx.x + i * 256;
         if (c < chunks) {
-            float wf[8], o[8];
+            float wf[8];
             unpack8(wraw[i], wf);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = v[i][j] * inv * wf[j];
-            out[r * chunks + c] = pack8(o);
+            for (int j = 0; j < 8; ++j) {
+                v[i][j] = round_h(v[i][j] * inv * wf[j]);
+                amax = fmaxf(amax, fabsf(v[i][j]));
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if ((threadIdx.x & 63) == 0) redq[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(redq[0], redq[1]), fmaxf(redq[2], redq[3]));
+    const float qinv = amax > 0.f ? 127.0f / amax : 0.f;
+    if (threadIdx.x == 0) sx[r] = amax / 127.0f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = threadIdx.x + i * 256;
+        if (c < chunks) {
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = fminf(fmaxf(rintf(v[i][j] * qinv), -127.f), 127.f), b = fminf(fmaxf(rintf(v[i][4 + j] * qinv), -127.f), 127.f);
+                lo |= (uint32_t)((int)a & 0xff) << (8 * j);
+                hi |= (uint32_t)((int)b & 0xff) << (8 * j);
+            }
+            *reinterpret_cast<uint2*>(qout + r * (int64_t)hidden + c * 8) = make_uint2(lo, hi);
         }
     }
 }
 
 hipError_t launch_rmsnorm(hipStream_t s, const uint16_t* x, const uint16_t* skip, const uint16_t* w, float eps,
                           int64_t rows, int hidden, const int64_t* gather_seq_starts, uint16_t* out,
-                          uint16_t* residual_out) {
+                          uint16_t* residual_out, int8_t* qout, float* sx) {
     if (rows == 0) return hipSuccess;
     const int chunks = hidden / 8;
     if (hidden % 8 || chunks > 256 * 8) return hipErrorInvalidValue;
     dim3 g((unsigned)rows), b(256);
 #define RMS_LAUNCH(MC)                                                                                              \
     hipLaunchKernelGGL(rmsnorm_kernel<MC>, g, b, 0, s, (const uint4*)x, (const uint4*)skip, (const uint4*)w, eps,   \
-                       chunks, hidden, gather_seq_starts, (uint4*)out, (uint4*)residual_out)
+                       chunks, hidden, gather_seq_starts, (uint4*)out, (uint4*)residual_out, qout, sx)
     if (chunks <= 256) RMS_LAUNCH(1);
     else if (chunks <= 512) RMS_LAUNCH(2);
     else if (chunks <= 1024) RMS_LAUNCH(4);

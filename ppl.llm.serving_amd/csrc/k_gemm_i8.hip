@@ -9,7 +9,8 @@
 // 4 x 4 tiles of v_mfma_i32_16x16x64_i8 (weights = A operand, so a lane owns 4 consecutive n of one activation row).
 // Both operands go global -> LDS by DMA into [row][128 B] tiles whose 16-byte chunk index is XOR-swizzled with
 // (row >> 1) & 7 on the source address and on the fragment reads (same scheme as the fp16 activation tile of k_gemm_dev.h).
-// Two LDS stages (64 KiB -> two blocks per CU), one barrier per K tile.
+// Two LDS stages (64 KiB -> two blocks per CU), one barrier per K tile; launches of <= 256 tiles use the 8-wave producer /
+// consumer form (gemm_i8_pc_kernel).
 // Skinny / generic kernel (any M, K % 16 == 0): one block per 16 weight rows, waves split K, weights straight from HBM
 // into the MFMA A operand, activations (L2 resident) into B; grid.y walks 32-row activation groups.
 #include <stdlib.h>
@@ -180,6 +181,111 @@ __global__ __launch_bounds__(256, 2) void gemm_i8_kernel(const int8_t* __restric
     }
 }
 
+// Producer / consumer form of the tile kernel: 8 waves, waves 0..3 multiply (2 x 2 layout as above), waves 4..7 do nothing but wait
+// for their LDS-DMA pieces and refill the ring (the ~100-cycle issue cost of a piece then runs beside the MFMA stream instead of in
+// front of it: int8 moves 8 pieces per 32 MFMAs and wave, more than the fp16 kernel).  ST stages of 32 KiB, one barrier per tile.
+template <int EPI, int ST>
+__global__ __launch_bounds__(512) void gemm_i8_pc_kernel(const int8_t* __restrict__ xq, const float* __restrict__ sx,
+                                                         const int8_t* __restrict__ w, const uint16_t* __restrict__ scale, int64_t M,
+                                                         int N, int K, void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem_i8[];  // ST x (X 16 KiB) then ST x (W 16 KiB)
+    constexpr int TILE = I_BM * I_BK;
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int nt = xcd + 8 * (slot / m_tiles);
+    const int mt = slot % m_tiles;
+    if (nt >= n_tiles) return;
+    const int n0 = nt * I_BN;
+    const int64_t m0 = (int64_t)mt * I_BM;
+    const bool producer = threadIdx.x >= 256;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int ktiles = K / I_BK;
+    constexpr int D = ST - 1, PT = 8;  // pieces per producer wave and tile
+
+    if (producer) {
+        const int8_t* xsrc[4];
+        const int8_t* wsrc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = j * 256 + tid, row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
+            int64_t m = m0 + row;
+            if (m >= M) m = M - 1;
+            int n = n0 + row;
+            if (n >= N) n = N - 1;
+            xsrc[j] = xq + m * K + c * 16;
+            wsrc[j] = w + (int64_t)n * K + c * 16;
+        }
+        const uint32_t xdst = __builtin_amdgcn_readfirstlane(lds_addr(smem_i8) + wave * 1024);
+        const uint32_t wdst = xdst + ST * TILE;
+        auto issue = [&](int stage, int k0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) glds16(xsrc[j] + k0, xdst + stage * TILE + j * 4096);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) glds16(wsrc[j] + k0, wdst + stage * TILE + j * 4096);
+        };
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (d < ktiles) issue(d, d * I_BK);
+        int stn = D % ST;
+        for (int t = 0; t < ktiles; ++t) {
+            const int younger = (ktiles - 1 - t) < (D - 1) ? (ktiles - 1 - t) : (D - 1);
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PT) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t + D < ktiles) issue(stn, (t + D) * I_BK);
+            stn = stn == ST - 1 ? 0 : stn + 1;
+        }
+        return;
+    }
+
+    const int wn = wave & 1, wm = wave >> 1;
+    i4v acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = i4v{0, 0, 0, 0};
+    int st = 0;
+    for (int t = 0; t < ktiles; ++t) {
+        __syncthreads();
+        const char* xs = smem_i8 + st * TILE;
+        const char* ws = smem_i8 + ST * TILE + st * TILE;
+        st = st == ST - 1 ? 0 : st + 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            i4v a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wn * 64 + i * 16 + l15;
+                a[i] = *reinterpret_cast<const i4v*>(ws + row * I_BK + g_swz(row, ks * 4 + kq) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wm * 64 + j * 16 + l15;
+                b[j] = *reinterpret_cast<const i4v*>(xs + row * I_BK + g_swz(row, ks * 4 + kq) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t m = m0 + wm * 64 + j * 16 + l15;
+        if (m >= M) continue;
+        const float sxm = sx[m];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + kq * 4;
+            if (n >= N) continue;
+            const h4 sh = __builtin_bit_cast(h4, *reinterpret_cast<const uint2*>(scale + n));
+            store4_i8<EPI>(yv, ldy, m, n, acc[i][j], sxm, sh);
+        }
+    }
+}
+
 // skinny / generic: block = NW waves = NW K slices of 16 weight rows; MT = 16-row activation tiles per block (grid.y walks M)
 template <int MT, int EPI, int NW>
 __global__ __launch_bounds__(NW * 64) void gemv_i8_kernel(const int8_t* __restrict__ xq, const float* __restrict__ sx,
@@ -282,6 +388,26 @@ hipError_t launch_linear_i8(hipStream_t s, const int8_t* xq, const float* sx, co
             attr_dev[dev & 63] = true;
         }
         dim3 grid((unsigned)((n_tiles + 7) / 8 * 8 * m_tiles));
+        // at most one block per CU (<= 256 tiles): the producer / consumer form (measured at M = 1024: wo 32.5 -> 28.6 us, w2 76.0 -> 51.4 us;
+        // with more tiles two 4-wave blocks per CU are faster: wqkv 61.9 vs 71.1 us).  PPLHIP_GEMM_I8_PC = 0 / 3 / 4 forces a form.
+        static const int forced_pc = getenv("PPLHIP_GEMM_I8_PC") ? atoi(getenv("PPLHIP_GEMM_I8_PC")) : -1;
+        const int pc = forced_pc >= 0 ? forced_pc : ((int64_t)n_tiles * m_tiles <= 256 ? 4 : 0);
+        if (pc == 3 || pc == 4) {
+            const size_t lds_pc = (size_t)pc * 2 * I_BM * I_BK;
+            static bool attr_pc[64] = {false};
+            if (!attr_pc[dev & 63]) {
+#define PCA(E) do { (void)hipFuncSetAttribute((const void*)gemm_i8_pc_kernel<E, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * I_BM * I_BK); \
+                    (void)hipFuncSetAttribute((const void*)gemm_i8_pc_kernel<E, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * I_BM * I_BK); } while (0)
+                PCA(EPI_F16); PCA(EPI_F32); PCA(EPI_SWIGLU);
+#undef PCA
+                attr_pc[dev & 63] = true;
+            }
+#define LPC(E) do { if (pc == 3) hipLaunchKernelGGL((gemm_i8_pc_kernel<E, 3>), grid, dim3(512), lds_pc, s, xq, sx, w, scale, M, N, K, y, ldy, n_tiles, m_tiles); \
+                    else hipLaunchKernelGGL((gemm_i8_pc_kernel<E, 4>), grid, dim3(512), lds_pc, s, xq, sx, w, scale, M, N, K, y, ldy, n_tiles, m_tiles); } while (0)
+            if (epi == EPI_F32) LPC(EPI_F32); else if (epi == EPI_F16) LPC(EPI_F16); else LPC(EPI_SWIGLU);
+#undef LPC
+            return hipGetLastError();
+        }
 #define LT(E) hipLaunchKernelGGL((gemm_i8_kernel<E>), grid, dim3(256), lds, s, xq, sx, w, scale, M, N, K, y, ldy, n_tiles, m_tiles)
         if (epi == EPI_F32) LT(EPI_F32); else if (epi == EPI_F16) LT(EPI_F16); else LT(EPI_SWIGLU);
 #undef LT

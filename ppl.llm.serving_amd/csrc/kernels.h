@@ -14,7 +14,7 @@ hipError_t launch_embedding(hipStream_t s, const int64_t* token_ids, const uint1
 // (last-token gather of K11), else src(r) = r.  residual_out (optional) receives fp16(x + skip) at row r.
 hipError_t launch_rmsnorm(hipStream_t s, const uint16_t* x, const uint16_t* skip, const uint16_t* w, float eps,
                           int64_t rows, int hidden, const int64_t* gather_seq_starts, uint16_t* out,
-                          uint16_t* residual_out);
+                          uint16_t* residual_out, int8_t* qout = nullptr, float* sx = nullptr);
 hipError_t launch_silu_mul(hipStream_t s, const uint16_t* gate_up, int64_t T, int inter, uint16_t* out);
 
 // ---- k_rope_kv.hip ----------------------------------------------------------------------------

@@ -1087,10 +1087,12 @@ struct Chunk {
 
 // one layer linear over a chunk: fp16 activations straight into the (weight-only quantised) GEMM, or -- online_i8i8 -- quantised
 // per token first and multiplied in int8.  x rows have stride l.Kp.
-static int layer_linear(pplhip_ctx* c, int rank, const Linear& l, const uint16_t* x, int64_t M, void* y, int64_t ldy, bool swiglu) {
+// pre_quantised: R.xq / R.sx already hold the rows (written by the RMSNorm in front of wqkv / w13).
+static int layer_linear(pplhip_ctx* c, int rank, const Linear& l, const uint16_t* x, int64_t M, void* y, int64_t ldy, bool swiglu,
+                        bool pre_quantised = false) {
     Rank& R = c->ranks[rank];
     if (c->d.act_quant_bit == 8) {
-        HIPCK(c, rank, launch_quant_act(R.stream, x, M, l.Kp, l.Kp, R.xq, l.Kp, R.sx));
+        if (!pre_quantised) HIPCK(c, rank, launch_quant_act(R.stream, x, M, l.Kp, l.Kp, R.xq, l.Kp, R.sx));
         HIPCK(c, rank, launch_linear_i8(R.stream, R.xq, R.sx, (const int8_t*)l.w, l.scale, M, l.N, l.Kp, y, ldy, false, swiglu));
         return 0;
     }
@@ -1109,10 +1111,11 @@ static int layer_attention_part(pplhip_ctx* c, int rank, int l, const Chunk& k, 
     ProfEvent ev;
     uint16_t* h = R.h + k.t0 * hd;
     uint16_t* xn = R.xn + k.t0 * hd;
+    const bool a8 = d.act_quant_bit == 8;  // the norm writes the int8 operand of the next linear directly (no fp16 xn, no separate pass)
     HIPCK(c, rank, launch_rmsnorm(s, h, pending ? pending + k.t0 * hd : nullptr, L.attn_norm, d.norm_eps, k.tn, hd, nullptr, xn,
-                                  pending ? h : nullptr));
+                                  pending ? h : nullptr, a8 ? R.xq : nullptr, a8 ? R.sx : nullptr));
     prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-    { int rc = layer_linear(c, rank, L.wqkv, xn, k.tn, R.qkv + k.t0 * nqkv, L.wqkv.N, false); if (rc) return rc; }
+    { int rc = layer_linear(c, rank, L.wqkv, xn, k.tn, R.qkv + k.t0 * nqkv, L.wqkv.N, false, a8); if (rc) return rc; }
     prof_end(R, &ev);
     const KvAddr kv = make_kv_addr(d, Hkv, D, R.kv_tokens, R.kv_cache, R.kv_scale, l);
     HIPCK(c, rank, launch_rope_kv_write(s, R.qkv, R.rope, kv, d.cache_quant_bit, d.cache_quant_group, R.d_seq, R.d_sp, R.d_ci,
@@ -1163,9 +1166,11 @@ static int layer_ffn_part(pplhip_ctx* c, int rank, int l, const Chunk& k) {
     uint16_t* h = R.h + k.t0 * hd;
     uint16_t* xn = R.xn + k.t0 * hd;
     uint16_t* act = R.act + k.t0 * (int64_t)L.w2.Kp;
-    HIPCK(c, rank, launch_rmsnorm(s, h, R.part + k.t0 * hd, L.ffn_norm, d.norm_eps, k.tn, hd, nullptr, xn, h));
+    const bool a8 = d.act_quant_bit == 8;
+    HIPCK(c, rank, launch_rmsnorm(s, h, R.part + k.t0 * hd, L.ffn_norm, d.norm_eps, k.tn, hd, nullptr, xn, h, a8 ? R.xq : nullptr,
+                                  a8 ? R.sx : nullptr));
     prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-    { int rc = layer_linear(c, rank, L.w13, xn, k.tn, act, L.w2.Kp, /*swiglu=*/true); if (rc) return rc; }
+    { int rc = layer_linear(c, rank, L.w13, xn, k.tn, act, L.w2.Kp, /*swiglu=*/true, a8); if (rc) return rc; }
     prof_end(R, &ev);
     prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
     { int rc = layer_linear(c, rank, L.w2, act, k.tn, R.part2 + k.t0 * hd, hd, false); if (rc) return rc; }
