@@ -388,21 +388,24 @@ hipError_t launch_linear_i8(hipStream_t s, const int8_t* xq, const float* sx, co
             attr_dev[dev & 63] = true;
         }
         dim3 grid((unsigned)((n_tiles + 7) / 8 * 8 * m_tiles));
-        // at most one block per CU (<= 256 tiles): the producer / consumer form (measured at M = 1024: wo 32.5 -> 28.6 us, w2 76.0 -> 51.4 us;
-        // with more tiles two 4-wave blocks per CU are faster: wqkv 61.9 vs 71.1 us).  PPLHIP_GEMM_I8_PC = 0 / 3 / 4 forces a form.
+        // 8-wave producer / consumer blocks everywhere (measured at M = 1024 against the 4-wave kernel: wo 32.5 -> 28.6 us and
+        // w2 76.0 -> 51.4 us with a 4-stage ring, one block per CU; w13 116.6 -> 106.0 us with two stages, two blocks per CU; wqkv
+        // 62.1 vs 63.6 us; M = 2048 layer 502 -> 459 us, M = 8192 equal).  PPLHIP_GEMM_I8_PC = 0 (4-wave kernel) / 2 / 3 / 4 forces a form.
         static const int forced_pc = getenv("PPLHIP_GEMM_I8_PC") ? atoi(getenv("PPLHIP_GEMM_I8_PC")) : -1;
-        const int pc = forced_pc >= 0 ? forced_pc : ((int64_t)n_tiles * m_tiles <= 256 ? 4 : 0);
-        if (pc == 3 || pc == 4) {
+        const int pc = forced_pc >= 0 ? forced_pc : ((int64_t)n_tiles * m_tiles <= 256 ? 4 : 2);
+        if (pc == 2 || pc == 3 || pc == 4) {
             const size_t lds_pc = (size_t)pc * 2 * I_BM * I_BK;
             static bool attr_pc[64] = {false};
             if (!attr_pc[dev & 63]) {
 #define PCA(E) do { (void)hipFuncSetAttribute((const void*)gemm_i8_pc_kernel<E, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * I_BM * I_BK); \
-                    (void)hipFuncSetAttribute((const void*)gemm_i8_pc_kernel<E, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * I_BM * I_BK); } while (0)
+                    (void)hipFuncSetAttribute((const void*)gemm_i8_pc_kernel<E, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * I_BM * I_BK); \
+                    (void)hipFuncSetAttribute((const void*)gemm_i8_pc_kernel<E, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * I_BM * I_BK); } while (0)
                 PCA(EPI_F16); PCA(EPI_F32); PCA(EPI_SWIGLU);
 #undef PCA
                 attr_pc[dev & 63] = true;
             }
-#define LPC(E) do { if (pc == 3) hipLaunchKernelGGL((gemm_i8_pc_kernel<E, 3>), grid, dim3(512), lds_pc, s, xq, sx, w, scale, M, N, K, y, ldy, n_tiles, m_tiles); \
+#define LPC(E) do { if (pc == 2) hipLaunchKernelGGL((gemm_i8_pc_kernel<E, 2>), grid, dim3(512), lds_pc, s, xq, sx, w, scale, M, N, K, y, ldy, n_tiles, m_tiles); \
+                    else if (pc == 3) hipLaunchKernelGGL((gemm_i8_pc_kernel<E, 3>), grid, dim3(512), lds_pc, s, xq, sx, w, scale, M, N, K, y, ldy, n_tiles, m_tiles); \
                     else hipLaunchKernelGGL((gemm_i8_pc_kernel<E, 4>), grid, dim3(512), lds_pc, s, xq, sx, w, scale, M, N, K, y, ldy, n_tiles, m_tiles); } while (0)
             if (epi == EPI_F32) LPC(EPI_F32); else if (epi == EPI_F16) LPC(EPI_F16); else LPC(EPI_SWIGLU);
 #undef LPC
