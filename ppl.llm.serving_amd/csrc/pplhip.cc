@@ -1398,6 +1398,16 @@ int pplhip_sample(pplhip_ctx* c, const float* logits_device, const pplhip_sample
         if (temps_host) { HIPCK(c, 0, hipMemcpyAsync(R.d_temp, temps_host, B * 4, hipMemcpyHostToDevice, s)); temp_opt = R.d_temp; }
         if (a->top_p) { HIPCK(c, 0, hipMemcpyAsync(R.d_topp, a->top_p, B * 4, hipMemcpyHostToDevice, s)); topp_opt = R.d_topp; }
     }
+    static const bool trace = getenv("PPLHIP_SAMPLE_TRACE") != nullptr;  // diagnosis: what every sampling call was handed
+    if (trace) {
+        fprintf(stderr, "[sample] B %d top_k0 %d top_p0 %g changed %d penalty %d temps", B, a->default_top_k, a->default_top_p, a->req_list_changed, a->enable_penalty);
+        for (int i = 0; i < B && a->temperatures; ++i) fprintf(stderr, " %g", a->temperatures[i]);
+        fprintf(stderr, " top_p");
+        for (int i = 0; i < B && a->top_p; ++i) fprintf(stderr, " %g", a->top_p[i]);
+        fprintf(stderr, " top_k");
+        for (int i = 0; i < B && a->top_k; ++i) fprintf(stderr, " %d", a->top_k[i]);
+        fprintf(stderr, "\n");
+    }
     // post_processor.cc:179-183: unseeded rand() sequence (one default value, then one per row)
     const float default_rand = (float)rand() / (float)RAND_MAX;
     (void)default_rand;

@@ -13,7 +13,9 @@
 #include <thread>
 
 #include "tool_common.h"
+#include <map>
 #include "tokenizer/tokenizer_factory.h"
+#include "scenario.h"
 
 using namespace ppl::llm;
 using namespace ppl::common;
@@ -21,7 +23,8 @@ using namespace ppl::common;
 int main(int argc, char** argv) {
     tools::Args a;
     tools::DefineCommonFlags(&a);
-    a.Def("--workload", "prompts4", "prompts4 | samples1024");
+    a.Def("--workload", "prompts4", "prompts4 | samples1024 | scenario");
+    a.Def("--scenario-file", "", "scenario: request / generator description (tools/scenario.h), answers printed as one JSON line");
     a.Def("--num-requests", "1024", "samples1024: number of requests");
     a.Def("--max-seq-len", "1024", "samples1024: prompt + answer length cap (seqlen of the benchmark config)");
     if (!a.Parse(argc, argv)) return -1;
@@ -31,6 +34,18 @@ int main(int argc, char** argv) {
     GeneratorConfig gc;
     ModelConfig mc;
     if (!tools::FillConfigs(a, &rc, &gc, &mc)) return -1;
+    utils::JsonValue scn;
+    if (a.Str("--workload") == "scenario") {
+        if (!scenario::LoadScenario(a.Str("--scenario-file"), &scn)) {
+            std::cerr << "cannot read --scenario-file " << a.Str("--scenario-file") << "\n";
+            return -1;
+        }
+        scenario::ScenarioGeneratorConfig(scn, &gc);
+        rc.enable_penalty = gc.enable_penalty;
+        rc.max_running_batch = gc.max_running_batch;
+        rc.max_tokens_per_step = gc.max_tokens_per_step;
+        if (scn.Find("kv_cache_max_tokens")) rc.kv_cache_max_tokens_override = (uint64_t)scn.GetInt("kv_cache_max_tokens", 0);
+    }
 
     hip::HipResourceManager resource_manager;
     RetCode st = resource_manager.Init(mc, rc);
@@ -87,6 +102,8 @@ int main(int argc, char** argv) {
             for (int& t : *r->token_ids) t = tok(rng);
             requests.push_back(r);
         }
+    } else if (workload == "scenario") {
+        requests = scenario::ScenarioRequests<Request>(scn, mc.vocab_size);
     } else {
         std::cerr << "unknown --workload " << workload << "\n";
         return -1;
@@ -123,6 +140,15 @@ int main(int argc, char** argv) {
             std::cout << "\n";
         }
         std::cout << "generation time: " << generate_us / 1e3 << "ms" << std::endl;
+    } else if (workload == "scenario") {
+        std::map<uint64_t, std::vector<int>> tokens;
+        std::vector<uint64_t> failed;
+        for (auto& r : requests) {
+            auto& rec = conn.records()[r->id];
+            if (rec.failed) failed.push_back(r->id);
+            else tokens[r->id] = rec.tokens;
+        }
+        scenario::PrintScenarioResult(tokens, failed);
     } else {
         std::vector<double> ttft, tpot;
         uint64_t out_tokens = 0, in_tokens = 0, failed = 0;

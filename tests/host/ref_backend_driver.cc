@@ -8,7 +8,9 @@
 // generation_length 8 + i.  Output format = ppl.llm.serving_amd/tools/offline_inference --workload prompts4, whose tokens
 // (the repo's own generator + engine over the same libpplhip) tests/test_gpu_tools.py requires to be IDENTICAL.
 //
-//   ref_backend_driver <params.json> [tensor_parallel_size]
+//   ref_backend_driver <params.json> [tensor_parallel_size [scenario.json]]
+// With a scenario file (tools/scenario.h) the requests, sampling parameters and generator limits come from it and the answers are
+// printed as offline_inference --workload scenario prints them.
 #include <condition_variable>
 #include <fstream>
 #include <iostream>
@@ -18,6 +20,7 @@
 #include "generator/llm_generator.h"                                   // the reference's
 #include "../../ppl.llm.serving_amd/src/backends/hip_nn/hip_nn_backend.h"
 #include "../../ppl.llm.serving_amd/src/utils/mini_json.h"
+#include "../../ppl.llm.serving_amd/tools/scenario.h"
 
 using namespace ppl::llm;
 using namespace ppl::common;
@@ -38,6 +41,7 @@ public:
     void NotifyFailure(uint64_t id, RetCode, const std::string& msg) override {
         std::lock_guard<std::mutex> g(mu_);
         std::cerr << "request " << id << " failed: " << msg << "\n";
+        failed.push_back(id);
         ++done;
         cv_.notify_all();
     }
@@ -46,6 +50,7 @@ public:
         return cv_.wait_for(lk, std::chrono::milliseconds(ms), [&] { return done >= n; });
     }
     std::map<uint64_t, std::vector<int>> tokens;
+    std::vector<uint64_t> failed;
     size_t done = 0;
 
 private:
@@ -100,6 +105,19 @@ int main(int argc, char** argv) {
     gc.max_total_tokens_per_request = 8192;
     gc.max_tokens_per_step = 8192;
     gc.max_prefill_batch = 64;
+    utils::JsonValue scn;
+    const bool have_scenario = argc > 3;
+    if (have_scenario) {
+        if (!scenario::LoadScenario(argv[3], &scn)) {
+            std::cerr << "cannot read scenario " << argv[3] << "\n";
+            return 2;
+        }
+        scenario::ScenarioGeneratorConfig(scn, &gc);
+        rc.enable_penalty = gc.enable_penalty;
+        rc.max_running_batch = gc.max_running_batch;
+        ex.max_tokens_per_step = gc.max_tokens_per_step;
+        if (scn.Find("kv_cache_max_tokens")) ex.kv_cache_max_tokens = (uint64_t)scn.GetInt("kv_cache_max_tokens", 8192);
+    }
 
     hip_nn::Backend backend;
     if (backend.Init(mc, rc, ex) != RC_SUCCESS) {
@@ -118,6 +136,17 @@ int main(int argc, char** argv) {
             return 1;
         }
         std::vector<std::shared_ptr<Request>> reqs;
+        if (have_scenario) {
+            reqs = scenario::ScenarioRequests<Request>(scn, mc.vocab_size);
+            for (auto& r : reqs) gen.Process(r);
+            if (!conn.Wait(reqs.size(), 300000)) {
+                std::cerr << "timed out\n";
+                return 1;
+            }
+            for (uint64_t id : conn.failed) conn.tokens.erase(id);
+            scenario::PrintScenarioResult(conn.tokens, conn.failed);
+            return 0;
+        }
         for (size_t i = 0; i < prompts.size(); ++i) {
             auto r = std::make_shared<Request>(i, "", 1.0f, 8 + (uint32_t)i);
             r->token_ids = std::make_shared<std::vector<int>>();

@@ -126,3 +126,51 @@ def test_offline_inference_text_prompts_through_the_cpp_tokenizer():
     by_text = {t["text"]: t["ids"] for t in cases["texts"]}
     assert ptoks[0] == [cases["bos"]] + by_text["Hello, my name is"] and ptoks[1] == [cases["bos"]] + by_text["The president of the United States is"]
     assert [len(a) for a in atoks] == [8, 9, 10, 11]
+
+
+def _random_scenario(rng, vocab, prefix, penalty):
+    shared = rng.randint(3, vocab, size=int(rng.randint(8, 30))).tolist()
+    reqs = []
+    for i in range(int(rng.randint(6, 20))):
+        toks = rng.randint(3, vocab, size=int(rng.randint(1, 24))).tolist()
+        if rng.rand() < 0.6:
+            toks = shared[:int(rng.randint(1, len(shared) + 1))] + toks
+        # greedy: both tools start their generator thread before the requests arrive, so WHICH requests share a step is a race,
+        # and a stochastic sampler draws per (step, row) from one rand() sequence -- only greedy answers are a function of the
+        # request alone.  (The per-request temperature still reaches the kernel and must not change an argmax.)
+        r = {"id": i, "tokens": toks, "generation_length": int(rng.randint(1, 14)),
+             "temperature": float(rng.choice([1.0, 0.7, 1.3])), "top_k": 1, "top_p": float(rng.choice([0.0, 0.9])),
+             "early_stopping": bool(rng.rand() < 0.8)}
+        if penalty:
+            r.update(repetition_penalty=float(rng.choice([1.0, 1.2])), presence_penalty=float(rng.choice([0.0, 0.5])),
+                     frequency_penalty=float(rng.choice([0.0, 0.3])))
+        if rng.rand() < 0.3:
+            r["stop_tokens"] = rng.randint(3, vocab, size=40).tolist()
+        reqs.append(r)
+    gen = {"max_running_batch": int(rng.randint(2, 9)), "max_tokens_per_step": int(rng.choice([64, 128, 512])),
+           "max_prefill_batch": int(rng.randint(1, 5)), "max_cooldown_request": int(rng.randint(1, 4)),
+           "enable_prefix_cache": prefix, "enable_penalty": penalty, "stop_tokens": rng.randint(3, vocab, size=6).tolist()}
+    return {"generator": gen, "kv_cache_max_tokens": int(rng.choice([256, 1024])), "requests": reqs}
+
+
+@pytest.mark.parametrize("seed,prefix,penalty", [(0, False, False), (1, True, False), (2, False, True), (3, True, True), (4, False, False),
+                                                 (5, True, True)])
+def test_reference_stack_and_this_tree_agree_on_random_scenarios(tmp_path, seed, prefix, penalty):
+    """the reference's generator + engine (compiled in place) over hip_nn::Backend against this tree's generator + engine over
+    src/backends/hip, same libpplhip: random prompts with shared prefixes, KV pressure, global and per-request stop tokens,
+    early stopping on and off, per-request temperature, penalties, prefix cache -- every token of every request must be identical,
+    and so must the set of rejected requests"""
+    drv = os.path.join(PKG, "build", "ref_backend_driver")
+    if not os.path.exists(drv):
+        pytest.skip("build/ref_backend_driver is built only where the reference tree exists (make ref)")
+    cfg = json.load(open(CFG))
+    sc = _random_scenario(np.random.RandomState(seed), cfg["vocab_size"], prefix, penalty)
+    path = str(tmp_path / "scenario.json")
+    json.dump(sc, open(path, "w"))
+    mine = subprocess.check_output([tool("offline_inference"), "--model-param-path", CFG, "--synthetic-weights", "--workload", "scenario",
+                                    "--scenario-file", path], timeout=300, stderr=subprocess.DEVNULL).decode()
+    theirs = subprocess.check_output([drv, CFG, "1", path], timeout=300, stderr=subprocess.DEVNULL).decode()
+    a, b = json.loads(mine.strip().splitlines()[-1]), json.loads(theirs.strip().splitlines()[-1])
+    assert sorted(a["failed"]) == sorted(b["failed"])
+    assert a["tokens"] == b["tokens"]
+    assert len(a["tokens"]) + len(a["failed"]) == len(sc["requests"]) and len(a["tokens"]) >= 1
