@@ -1424,6 +1424,17 @@ int pplhip_sample(pplhip_ctx* c, const float* logits_device, const pplhip_sample
     HIPCK(c, 0, hipMemcpyAsync(output_host, R.d_tokout, B * 4, hipMemcpyDeviceToHost, s));
     HIPCK(c, 0, hipMemcpyAsync(logprob_host, R.d_lp, B * 4, hipMemcpyDeviceToHost, s));
     HIPCK(c, 0, hipStreamSynchronize(s));  // the step's only host<->device synchronisation (post_processor.cc:212)
+    if (trace) {
+        std::vector<float> row(a->vocab_size);
+        for (int i = 0; i < B; ++i) {
+            (void)hipMemcpy(row.data(), logits_device + (size_t)i * a->batch_stride, (size_t)a->vocab_size * 4, hipMemcpyDeviceToHost);
+            double sum = 0;
+            int am = 0;
+            for (int v = 0; v < a->vocab_size; ++v) { sum += row[v]; if (row[v] > row[am]) am = v; }
+            fprintf(stderr, "[sample]   row %d -> token %d logprob %.6f | logits sum %.6f argmax %d (%.6f) rand %.8f\n", i, output_host[i], logprob_host[i], sum, am,
+                    row[am], R.h_rand[i]);
+        }
+    }
     return p2p_check(c, 0);
 }
 

@@ -138,6 +138,7 @@ int main(int argc, char** argv) {
         std::vector<std::shared_ptr<Request>> reqs;
         if (have_scenario) {
             reqs = scenario::ScenarioRequests<Request>(scn, mc.vocab_size);
+            srand(1);  // as offline_inference --workload scenario: both processes then draw the same rand() numbers in the sampler
             for (auto& r : reqs) gen.Process(r);
             if (!conn.Wait(reqs.size(), 300000)) {
                 std::cerr << "timed out\n";

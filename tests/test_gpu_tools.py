@@ -128,7 +128,7 @@ def test_offline_inference_text_prompts_through_the_cpp_tokenizer():
     assert [len(a) for a in atoks] == [8, 9, 10, 11]
 
 
-def _random_scenario(rng, vocab, prefix, penalty):
+def _random_scenario(rng, vocab, prefix, penalty, stochastic=False):
     shared = rng.randint(3, vocab, size=int(rng.randint(8, 30))).tolist()
     reqs = []
     for i in range(int(rng.randint(6, 20))):
@@ -150,12 +150,19 @@ def _random_scenario(rng, vocab, prefix, penalty):
     gen = {"max_running_batch": int(rng.randint(2, 9)), "max_tokens_per_step": int(rng.choice([64, 128, 512])),
            "max_prefill_batch": int(rng.randint(1, 5)), "max_cooldown_request": int(rng.randint(1, 4)),
            "enable_prefix_cache": prefix, "enable_penalty": penalty, "stop_tokens": rng.randint(3, vocab, size=6).tolist()}
+    if stochastic:
+        # one request at a time: the step composition is then fixed (FIFO), and so is the position of every draw in the sampler's
+        # unseeded rand() sequence (post_processor.cc:179-183) -- per-request temperature / top-p and top_k_list[0] (Q3) must agree
+        gen["max_running_batch"] = 1
+        for r in reqs:
+            r["top_k"] = int(rng.choice([1, 8, 40]))
     return {"generator": gen, "kv_cache_max_tokens": int(rng.choice([256, 1024])), "requests": reqs}
 
 
-@pytest.mark.parametrize("seed,prefix,penalty", [(0, False, False), (1, True, False), (2, False, True), (3, True, True), (4, False, False),
-                                                 (5, True, True)])
-def test_reference_stack_and_this_tree_agree_on_random_scenarios(tmp_path, seed, prefix, penalty):
+@pytest.mark.parametrize("seed,prefix,penalty,stochastic", [(0, False, False, False), (1, True, False, False), (2, False, True, False),
+                                                            (3, True, True, False), (4, False, False, False), (5, True, True, False),
+                                                            (6, False, False, True), (7, False, True, True), (8, True, False, True)])
+def test_reference_stack_and_this_tree_agree_on_random_scenarios(tmp_path, seed, prefix, penalty, stochastic):
     """the reference's generator + engine (compiled in place) over hip_nn::Backend against this tree's generator + engine over
     src/backends/hip, same libpplhip: random prompts with shared prefixes, KV pressure, global and per-request stop tokens,
     early stopping on and off, per-request temperature, penalties, prefix cache -- every token of every request must be identical,
@@ -164,7 +171,7 @@ def test_reference_stack_and_this_tree_agree_on_random_scenarios(tmp_path, seed,
     if not os.path.exists(drv):
         pytest.skip("build/ref_backend_driver is built only where the reference tree exists (make ref)")
     cfg = json.load(open(CFG))
-    sc = _random_scenario(np.random.RandomState(seed), cfg["vocab_size"], prefix, penalty)
+    sc = _random_scenario(np.random.RandomState(seed), cfg["vocab_size"], prefix, penalty, stochastic)
     path = str(tmp_path / "scenario.json")
     json.dump(sc, open(path, "w"))
     mine = subprocess.check_output([tool("offline_inference"), "--model-param-path", CFG, "--synthetic-weights", "--workload", "scenario",
