@@ -174,9 +174,12 @@ def test_reference_stack_and_this_tree_agree_on_random_scenarios(tmp_path, seed,
     sc = _random_scenario(np.random.RandomState(seed), cfg["vocab_size"], prefix, penalty, stochastic)
     path = str(tmp_path / "scenario.json")
     json.dump(sc, open(path, "w"))
+    tp = 2 if seed in (3, 7) else 1          # two of the cases tensor-parallel (both ranks on device 0, direct collectives)
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="24", PPLHIP_DEVICE_IDS=",".join(["0"] * tp))
     mine = subprocess.check_output([tool("offline_inference"), "--model-param-path", CFG, "--synthetic-weights", "--workload", "scenario",
-                                    "--scenario-file", path], timeout=300, stderr=subprocess.DEVNULL).decode()
-    theirs = subprocess.check_output([drv, CFG, "1", path], timeout=300, stderr=subprocess.DEVNULL).decode()
+                                    "--scenario-file", path, "--tensor-parallel-size", str(tp)], timeout=300, stderr=subprocess.DEVNULL,
+                                   env=env).decode()
+    theirs = subprocess.check_output([drv, CFG, str(tp), path], timeout=300, stderr=subprocess.DEVNULL, env=env).decode()
     a, b = json.loads(mine.strip().splitlines()[-1]), json.loads(theirs.strip().splitlines()[-1])
     assert sorted(a["failed"]) == sorted(b["failed"])
     assert a["tokens"] == b["tokens"]
