@@ -286,6 +286,104 @@ __global__ __launch_bounds__(512) void gemm_i8_pc_kernel(const int8_t* __restric
     }
 }
 
+// Large M (steps that carry prefill): 256(n) x 256(m) x 64(k) tiles, 8 waves as 4 (n) x 2 (m), wave tile 64 x 128 = 4 x 8 MFMA tiles
+// (12 fragment reads and 4 LDS-DMA pieces per 32 MFMAs and wave, against 16 and 8 in the 128 x 128 kernels), 64-byte rows with the
+// w_swz chunk swizzle for both operands, ST-stage ring of 32 KiB, one barrier per tile, one block per CU.
+template <int EPI, int ST>
+__global__ __launch_bounds__(512) void gemm_i8_256_kernel(const int8_t* __restrict__ xq, const float* __restrict__ sx,
+                                                          const int8_t* __restrict__ w, const uint16_t* __restrict__ scale, int64_t M,
+                                                          int N, int K, void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem_i8[];  // ST x (X 16 KiB) then ST x (W 16 KiB)
+    constexpr int TILE = 256 * 64;
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int nt = xcd + 8 * (slot / m_tiles);
+    const int mt = slot % m_tiles;
+    if (nt >= n_tiles) return;
+    const int n0 = nt * 256;
+    const int64_t m0 = (int64_t)mt * 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int wn = wave & 3, wm = wave >> 2;
+
+    const int8_t* xsrc[2];
+    const int8_t* wsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = j * 512 + tid, row = p >> 2, c = (p & 3) ^ w_swz(row);
+        int64_t m = m0 + row;
+        if (m >= M) m = M - 1;
+        int n = n0 + row;
+        if (n >= N) n = N - 1;
+        xsrc[j] = xq + m * K + c * 16;
+        wsrc[j] = w + (int64_t)n * K + c * 16;
+    }
+    const uint32_t xdst = __builtin_amdgcn_readfirstlane(lds_addr(smem_i8) + wave * 1024);
+    const uint32_t wdst = xdst + ST * TILE;
+    auto issue = [&](int stage, int k0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(xsrc[j] + k0, xdst + stage * TILE + j * 8192);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(wsrc[j] + k0, wdst + stage * TILE + j * 8192);
+    };
+    int woff[4], xoff[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wn * 64 + i * 16 + l15;
+        woff[i] = ST * TILE + row * 64 + (kq ^ w_swz(row)) * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = wm * 128 + j * 16 + l15;
+        xoff[j] = row * 64 + (kq ^ w_swz(row)) * 16;
+    }
+    i4v acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = i4v{0, 0, 0, 0};
+
+    constexpr int D = ST - 1, PT = 4;
+    const int ktiles = K / 64;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < ktiles) issue(d, d * 64);
+    int st = 0, stn = D % ST;
+    for (int t = 0; t < ktiles; ++t) {
+        const int younger = (ktiles - 1 - t) < (D - 1) ? (ktiles - 1 - t) : (D - 1);
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PT) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + D < ktiles) issue(stn, (t + D) * 64);
+        const char* sb = smem_i8 + st * TILE;
+        st = st == ST - 1 ? 0 : st + 1;
+        stn = stn == ST - 1 ? 0 : stn + 1;
+        i4v a[4], b[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const i4v*>(sb + woff[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = *reinterpret_cast<const i4v*>(sb + xoff[j]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int64_t m = m0 + wm * 128 + j * 16 + l15;
+        if (m >= M) continue;
+        const float sxm = sx[m];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + kq * 4;
+            if (n >= N) continue;
+            const h4 sh = __builtin_bit_cast(h4, *reinterpret_cast<const uint2*>(scale + n));
+            store4_i8<EPI>(yv, ldy, m, n, acc[i][j], sxm, sh);
+        }
+    }
+}
+
 // skinny / generic: block = NW waves = NW K slices of 16 weight rows; MT = 16-row activation tiles per block (grid.y walks M)
 template <int MT, int EPI, int NW>
 __global__ __launch_bounds__(NW * 64) void gemv_i8_kernel(const int8_t* __restrict__ xq, const float* __restrict__ sx,
@@ -391,6 +489,26 @@ hipError_t launch_linear_i8(hipStream_t s, const int8_t* xq, const float* sx, co
         // 8-wave producer / consumer blocks everywhere (measured at M = 1024 against the 4-wave kernel: wo 32.5 -> 28.6 us and
         // w2 76.0 -> 51.4 us with a 4-stage ring, one block per CU; w13 116.6 -> 106.0 us with two stages, two blocks per CU; wqkv
         // 62.1 vs 63.6 us; M = 2048 layer 502 -> 459 us, M = 8192 equal).  PPLHIP_GEMM_I8_PC = 0 (4-wave kernel) / 2 / 3 / 4 forces a form.
+        static const int min_m256 = getenv("PPLHIP_GEMM_I8_256_MIN_M") ? atoi(getenv("PPLHIP_GEMM_I8_256_MIN_M")) : 4096;  // measured: M = 4096 layer 888 us (1.87 POP/s) vs 1110, M = 2048 554 vs 459 us
+        if (M >= min_m256 && N >= 1024) {
+            const int nt2 = (N + 255) / 256, mt2 = (int)((M + 255) / 256);
+            static const int st256 = getenv("PPLHIP_GEMM_I8_256_ST") ? atoi(getenv("PPLHIP_GEMM_I8_256_ST")) : 4;
+            const size_t lds2 = (size_t)(st256 == 3 ? 3 : 4) * 2 * 256 * 64;
+            static bool attr2[64] = {false};
+            if (!attr2[dev & 63]) {
+#define A2(E) do { (void)hipFuncSetAttribute((const void*)gemm_i8_256_kernel<E, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 256 * 64); \
+                   (void)hipFuncSetAttribute((const void*)gemm_i8_256_kernel<E, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 256 * 64); } while (0)
+                A2(EPI_F16); A2(EPI_F32); A2(EPI_SWIGLU);
+#undef A2
+                attr2[dev & 63] = true;
+            }
+            dim3 g2((unsigned)((nt2 + 7) / 8 * 8 * mt2));
+#define L2(E) do { if (st256 == 3) hipLaunchKernelGGL((gemm_i8_256_kernel<E, 3>), g2, dim3(512), lds2, s, xq, sx, w, scale, M, N, K, y, ldy, nt2, mt2); \
+                   else hipLaunchKernelGGL((gemm_i8_256_kernel<E, 4>), g2, dim3(512), lds2, s, xq, sx, w, scale, M, N, K, y, ldy, nt2, mt2); } while (0)
+            if (epi == EPI_F32) L2(EPI_F32); else if (epi == EPI_F16) L2(EPI_F16); else L2(EPI_SWIGLU);
+#undef L2
+            return hipGetLastError();
+        }
         static const int forced_pc = getenv("PPLHIP_GEMM_I8_PC") ? atoi(getenv("PPLHIP_GEMM_I8_PC")) : -1;
         const int pc = forced_pc >= 0 ? forced_pc : ((int64_t)n_tiles * m_tiles <= 256 ? 4 : 2);
         if (pc == 2 || pc == 3 || pc == 4) {
