@@ -139,6 +139,7 @@ def serving_leg(model_kw, args):
     exe = os.path.join(ROOT, "ppl.llm.serving_amd", "build", "offline_inference")
     if not os.path.exists(exe):
         return {"error": "build/offline_inference missing (run __graft_entry__.build())"}
+    paced = None
     with tempfile.TemporaryDirectory() as td:
         params = dict(num_heads=model_kw["num_heads"], num_kv_heads=model_kw["num_kv_heads"], num_layers=model_kw["num_layers"],
                       hidden_dim=model_kw["hidden_dim"], intermediate_dim=model_kw["intermediate_dim"], vocab_size=model_kw["vocab_size"],
@@ -154,6 +155,20 @@ def serving_leg(model_kw, args):
         t0 = time.time()
         out = subprocess.run(cmd, capture_output=True, timeout=900)
         wall = time.time() - t0
+        # the same load at a finite arrival rate (client_qps_measure's --request_rate): what a request sees when the server is
+        # not handed its whole day's work at once -- a short second run, 256 requests
+        if out.returncode == 0 and not args.no_paced_leg:
+            cmd2 = [exe, "--model-param-path", path, "--synthetic-weights", "--workload", "samples1024", "--num-requests", "256",
+                    "--request-rate", "64", "--max-seq-len", "1024", "--max-running-batch", str(args.batch), "--max-tokens-per-step", "8192"]
+            if args.act_quant == 8:
+                cmd2 += ["--quant-method", "online_i8i8"]
+            out2 = subprocess.run(cmd2, capture_output=True, timeout=900)
+            l2 = [l for l in out2.stdout.decode().splitlines() if l.startswith("{")]
+            if out2.returncode == 0 and l2:
+                r2 = json.loads(l2[-1])
+                paced = {"workload": "256 requests, Poisson arrivals at 64 requests/s", "failed": r2["failed"], "ttft_p50_ms": r2["ttft_ms"]["p50"],
+                         "ttft_p90_ms": r2["ttft_ms"]["p90"], "ttft_p99_ms": r2["ttft_ms"]["p99"],
+                         "decode_ms_per_token_p50": r2["decode_ms_per_token"]["p50"], "tokens_out_per_s": r2["tokens_out_per_s"]}
     lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
     if out.returncode != 0 or not lines:
         return {"error": f"offline_inference rc {out.returncode}: {out.stderr.decode()[-300:]}"}
@@ -161,7 +176,7 @@ def serving_leg(model_kw, args):
     return {"workload": r["workload"] + ", submitted at once, max-running-batch %d" % args.batch, "requests": r["requests"], "failed": r["failed"],
             "tokens_out_per_s": r["tokens_out_per_s"], "ttft_p50_ms": r["ttft_ms"]["p50"], "ttft_p90_ms": r["ttft_ms"]["p90"],
             "ttft_p99_ms": r["ttft_ms"]["p99"], "decode_ms_per_token_p50": r["decode_ms_per_token"]["p50"], "steps": r["steps"],
-            "max_running": r["max_running"], "process_wall_s": round(wall, 1)}
+            "max_running": r["max_running"], "process_wall_s": round(wall, 1), "paced": paced}
 
 
 def dry_run(args, P, dist, rank, world):
@@ -251,6 +266,7 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="debug only: override the layer count (result is then INVALID)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serving-leg", action="store_true", help="skip the samples_1024-shaped serving run (TTFT)")
+    ap.add_argument("--no-paced-leg", action="store_true", help="serving leg: skip the second run at 64 requests/s")
     ap.add_argument("--breakdown", action="store_true",
                     help="also time the GEMM launches (events around every kernel class: costs the step ~3 %%; default: decode attention only)")
     ap.add_argument("--no-i8i8-leg", action="store_true",

@@ -27,6 +27,8 @@ int main(int argc, char** argv) {
     a.Def("--scenario-file", "", "scenario: request / generator description (tools/scenario.h), answers printed as one JSON line");
     a.Def("--num-requests", "1024", "samples1024: number of requests");
     a.Def("--max-seq-len", "1024", "samples1024: prompt + answer length cap (seqlen of the benchmark config)");
+    a.Def("--request-rate", "0", "samples1024: Poisson arrivals at this many requests per second (0: all submitted at once), as "
+                                 "client_qps_measure's --request_rate");
     if (!a.Parse(argc, argv)) return -1;
     if (a.Bool("--help")) { a.PrintHelp(); return 0; }
 
@@ -126,7 +128,14 @@ int main(int argc, char** argv) {
     const auto t_begin = tools::Clock::now();
     {
         utils::TimingGuard timing(&generate_us);
+        const double rate = a.Num("--request-rate");
+        std::exponential_distribution<double> gap(rate > 0 ? rate : 1.0);
+        auto next = tools::Clock::now();
         for (auto& r : requests) {
+            if (rate > 0 && workload == "samples1024") {  // client_qps_measure.cc: exponential inter-arrival times
+                std::this_thread::sleep_until(next);
+                next += std::chrono::duration_cast<tools::Clock::duration>(std::chrono::duration<double>(gap(rng)));
+            }
             conn.MarkSubmit(r->id);
             generator->Process(r);
         }
@@ -172,13 +181,13 @@ int main(int argc, char** argv) {
         const auto& g = prof.step_counter.global;
         char buf[2048];
         snprintf(buf, sizeof(buf),
-                 "{\"workload\":\"samples1024-shaped token-in/out, %zu requests, seed %lld\",\"requests\":%zu,\"failed\":%llu,"
+                 "{\"workload\":\"samples1024-shaped token-in/out, %zu requests, seed %lld\",\"request_rate\":%g,\"requests\":%zu,\"failed\":%llu,"
                  "\"input_tokens\":%llu,\"output_tokens\":%llu,\"wall_s\":%.4f,\"tokens_out_per_s\":%.2f,"
                  "\"generator_tps\":%.2f,\"steps\":%llu,\"max_running\":%llu,"
                  "\"ttft_ms\":{\"min\":%.2f,\"p10\":%.2f,\"p25\":%.2f,\"p50\":%.2f,\"p75\":%.2f,\"p90\":%.2f,\"p99\":%.2f,\"max\":%.2f},"
                  "\"decode_ms_per_token\":{\"p50\":%.3f,\"p90\":%.3f,\"p99\":%.3f},"
                  "\"phase_ms\":{\"prepare\":%.1f,\"set_input\":%.1f,\"model_forward\":%.1f,\"choose_token\":%.1f,\"post_process\":%.1f,\"total\":%.1f}}",
-                 requests.size(), a.I64("--seed"), requests.size(), (unsigned long long)failed, (unsigned long long)in_tokens,
+                 requests.size(), a.I64("--seed"), a.Num("--request-rate"), requests.size(), (unsigned long long)failed, (unsigned long long)in_tokens,
                  (unsigned long long)out_tokens, wall_s, out_tokens / wall_s,
                  g.total_cost ? g.output_token_cnt / (g.total_cost / 1e6) : 0.0, (unsigned long long)g.step_cnt,
                  (unsigned long long)prof.max_running_task, tools::Percentile(ttft, 0), tools::Percentile(ttft, 10),
