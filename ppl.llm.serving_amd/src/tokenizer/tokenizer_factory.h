@@ -40,13 +40,15 @@ private:
     SentencePieceModel sp_;
 };
 
-// reference src/tokenizer/models/llama/llama_tokenizer.h:28-52 (internlm / baichuan wrap the same way)
+// The model family's policy around a tokenizer implementation (reference src/tokenizer/models/*/ *_tokenizer.h): llama, internlm and
+// llama3 put BOS in front of every prompt (models/llama/llama_tokenizer.h:35-38, internlm_tokenizer.h, llama3_tokenizer.h),
+// baichuan encodes the prompt as it is (models/baichuan/baichuan_tokenizer.h).
 class LlamaTokenizer final : public Tokenizer {
 public:
-    explicit LlamaTokenizer(Tokenizer* impl) : impl_(impl) {}
+    explicit LlamaTokenizer(Tokenizer* impl, bool prepend_bos = true) : impl_(impl), prepend_bos_(prepend_bos) {}
     void Encode(const char* prompt, uint32_t len, std::vector<int>* token_ids) const override {
         impl_->Encode(prompt, len, token_ids);
-        token_ids->insert(token_ids->begin(), impl_->GetBosId());
+        if (prepend_bos_) token_ids->insert(token_ids->begin(), impl_->GetBosId());
     }
     void Decode(int* token_ids, uint32_t len, std::string* output) const override { impl_->Decode(token_ids, len, output); }
     int GetBosId() const override { return impl_->GetBosId(); }
@@ -54,6 +56,7 @@ public:
 
 private:
     std::unique_ptr<Tokenizer> impl_;
+    bool prepend_bos_;
 };
 
 class TokenizerFactory final {
@@ -66,7 +69,8 @@ public:
         }
         std::unique_ptr<SentencePieceTokenizer> impl(new SentencePieceTokenizer());
         if (!impl->Init(tokenizer_path)) return nullptr;
-        if (model_type == "llama" || model_type == "internlm" || model_type == "baichuan") return new LlamaTokenizer(impl.release());
+        if (model_type == "llama" || model_type == "internlm" || model_type == "llama3") return new LlamaTokenizer(impl.release(), true);
+        if (model_type == "baichuan") return new LlamaTokenizer(impl.release(), false);
         LOG(ERROR) << "not supported model: " << model_type;
         return nullptr;
     }

@@ -2,6 +2,7 @@
 //   E <hex utf-8 text>   -> the ids of SentencePieceModel::Encode, space separated
 //   D <id> <id> ...      -> hex of SentencePieceModel::Decode
 //   L <hex text>         -> ids of LlamaTokenizer::Encode (BOS first; reference models/llama/llama_tokenizer.h:35-38)
+//   B <hex text>         -> ids of the "baichuan" policy (no BOS; models/baichuan/baichuan_tokenizer.h)
 //   T <id>               -> hex of the one-token decode the generator uses (leading-space rule of tokenizer_impl_sp.h:53-59)
 #include <iostream>
 #include <sstream>
@@ -28,18 +29,20 @@ int main(int argc, char** argv) {
     std::string err;
     if (!sp.Load(argv[1], &err)) { std::cout << "ERROR " << err << std::endl; return 1; }
     std::unique_ptr<Tokenizer> tok(TokenizerFactory::Create("llama", "sentencepiece", argv[1], ""));
-    if (!tok) { std::cout << "ERROR factory" << std::endl; return 1; }
+    std::unique_ptr<Tokenizer> tok_b(TokenizerFactory::Create("baichuan", "sentencepiece", argv[1], ""));
+    if (!tok || !tok_b) { std::cout << "ERROR factory" << std::endl; return 1; }
     std::cout << "OK " << sp.GetPieceSize() << " " << sp.bos_id() << " " << sp.eos_id() << " " << sp.unk_id() << std::endl;
     std::string line;
     while (std::getline(std::cin, line)) {
         if (line.empty()) continue;
         std::istringstream ss(line.substr(1));
-        if (line[0] == 'E' || line[0] == 'L') {
+        if (line[0] == 'E' || line[0] == 'L' || line[0] == 'B') {
             std::string hex;
             ss >> hex;
             const std::string text = FromHex(hex);
             std::vector<int> ids;
             if (line[0] == 'E') sp.Encode(text.data(), text.size(), &ids);
+            else if (line[0] == 'B') tok_b->Encode(text.data(), (uint32_t)text.size(), &ids);
             else tok->Encode(text.data(), (uint32_t)text.size(), &ids);
             for (size_t i = 0; i < ids.size(); ++i) std::cout << (i ? " " : "") << ids[i];
             std::cout << std::endl;

@@ -72,6 +72,15 @@ def test_llama_policy_bos_and_streaming_pieces(tool, cases):
     assert "".join(streamed).replace(" ", "") == t["text"].replace(" ", "") and "".join(streamed).startswith(" The")
 
 
+def test_baichuan_policy_has_no_bos(tool, cases):
+    """models/baichuan/baichuan_tokenizer.h encodes the prompt as it is; llama / internlm / llama3 put BOS first"""
+    c = cases["spm_bpe.model"]
+    t = next(x for x in c["texts"] if x["text"] == "Hello, my name is")
+    _, rows = run(tool, "spm_bpe.model", ["B " + hexs(t["text"]), "L " + hexs(t["text"])])
+    assert [int(x) for x in rows[0].split()] == t["ids"]
+    assert [int(x) for x in rows[1].split()] == [c["bos"]] + t["ids"]
+
+
 def test_unsupported_models_are_refused(tool, tmp_path):
     bad = tmp_path / "garbage.model"
     bad.write_bytes(b"\x00\x01\x02not a model")
