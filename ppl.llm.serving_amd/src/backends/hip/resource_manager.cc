@@ -107,6 +107,16 @@ static RetCode InitRank(uint32_t id, pplhip_ctx* ctx, const ResourceConfig& rc, 
     }
     if (st) {
         LOG(ERROR) << "load weights of rank [" << id << "] failed: " << pplhip_last_error(ctx, (int)id);
+        if (!rc.synthetic_weights) {
+            // a ppl.pmx export (model_slice_<r>/model.onnx, the reference's --model-format onnx / pmx) is converted once, offline
+            const std::string onnx = rc.model_dir + "/model_slice_" + std::to_string(id) + "/model.onnx";
+            if (FILE* f = fopen(onnx.c_str(), "rb")) {
+                fclose(f);
+                LOG(ERROR) << rc.model_dir << " holds a ppl.pmx export (model.onnx): convert it with "
+                           << "`python ppl.llm.serving_amd/tools/import_pmx_onnx.py --model-dir " << rc.model_dir
+                           << " --out <dir> --quant {none,w8a16,w4a16}` and pass the result as --model-dir";
+            }
+        }
         barrier->Wait();
         return FromPplHipStatus(st);
     }

@@ -18,7 +18,7 @@ namespace tools {
 inline void DefineCommonFlags(Args* a) {
     a->Def("--help", "false", "show this help", true);
     a->Def("--model-type", "llama", "");
-    a->Def("--model-format", "pplhip", "weights.pplhip slices (the reference loads onnx/pmx through ppl.nn)");
+    a->Def("--model-format", "pplhip", "weights.pplhip slices (a ppl.pmx export, the reference's onnx / pmx, is converted by tools/import_pmx_onnx.py)");
     a->Def("--model-dir", "", "directory holding model_slice_<rank>/weights.pplhip");
     a->Def("--model-param-path", "", "params.json");
     a->Def("--tensor-parallel-size", "1", "");
@@ -48,6 +48,12 @@ inline void DefineCommonFlags(Args* a) {
     a->Def("--enable-prefix-cache", "false", "is enable prefix cache", true);
     a->Def("--max-prefill-batch", "64", "max prefill batches per step");
     a->Def("--enable-profiling", "false", "print profiling message", true);
+    // flags of the reference's tools that only its server reads: accepted so that a command line carries over unchanged
+    a->Def("--host", "127.0.0.1", "accepted; the offline tools open no socket");
+    a->Def("--port", "10086", "accepted; ignored");
+    a->Def("--monitor-port", "23333", "accepted; ignored");
+    a->Def("--control-port", "12345", "accepted; ignored");
+    a->Def("--version", "false", "accepted; ignored", true);
     // additions of this build
     a->Def("--synthetic-weights", "false", "fill the model slices with the synthetic generator instead of loading", true);
     a->Def("--synthetic-seed", "1234", "");
