@@ -10,7 +10,7 @@ Requests: `--dataset file.json` ([{"input_ids": [...], "max_new_tokens": n}, ...
 workload of SURVEY.md 8(d) D2 (log-normal prompt / answer lengths, seed 1234), the same one `offline_inference --workload
 samples1024` runs in process.
 
-    python client_qps_measure_token_in_out.py --target 127.0.0.1:23333 --num-requests 1024 --request-rate inf
+    python client_qps_measure_token_in_out.py --target 127.0.0.1:10086 --num-requests 1024 --request-rate inf
 """
 import argparse
 import asyncio
@@ -105,7 +105,7 @@ async def run(a):
 
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("--target", default="127.0.0.1:23333")
+    ap.add_argument("--target", default="127.0.0.1:10086")
     ap.add_argument("--dataset", default="")
     ap.add_argument("--num-requests", type=int, default=1024)
     ap.add_argument("--request-rate", default="inf", help='requests per second (Poisson arrivals) or "inf"')

@@ -14,7 +14,7 @@ Behaviour kept from grpc_server.cc:
   * a rejected request answers {status FAILED, id} (:137-150); the stream ends when every request of the call finished;
   * a client that goes away cancels its unfinished requests (NewCallThreadFunc -> on_disconnected_func, :293-312).
 
-    python grpc_server.py --model-param-path params.json --model-dir <dir> [--host 0.0.0.0 --port 23333] [tool flags]
+    python grpc_server.py --model-param-path params.json --model-dir <dir> [--host 127.0.0.1 --port 10086] [tool flags]
 """
 import argparse
 import asyncio
@@ -40,7 +40,8 @@ class Config(C.Structure):
                 ("max_total_tokens_per_request", C.c_int32), ("max_prefill_batch", C.c_int32), ("max_cooldown_request", C.c_int32),
                 ("enable_prefix_cache", C.c_int32), ("enable_penalty", C.c_int32), ("stop_tokens", C.POINTER(C.c_int32)),
                 ("n_stop_tokens", C.c_int32), ("tokenizer_path", C.c_char_p), ("tokenizer_type", C.c_char_p),
-                ("model_type", C.c_char_p), ("quant_method", C.c_char_p)]
+                ("model_type", C.c_char_p), ("quant_method", C.c_char_p), ("top_p", C.c_float), ("top_k", C.c_int32),
+                ("decoding_attn_split_k", C.c_int32), ("decoding_attn_tpb", C.c_int32)]
 
 
 class CRequest(C.Structure):
@@ -222,7 +223,9 @@ def make_config(a):
                  max_cooldown_request=a.max_cooldown_request, enable_prefix_cache=int(a.enable_prefix_cache),
                  enable_penalty=int(a.enable_penalty), stop_tokens=arr, n_stop_tokens=len(stop),
                  tokenizer_path=(a.tokenizer_path or "").encode(), tokenizer_type=(a.tokenizer_type or "sentencepiece").encode(),
-                 model_type=(a.model_type or "llama").encode(), quant_method=(a.quant_method or "none").encode())
+                 model_type=(a.model_type or "llama").encode(), quant_method=(a.quant_method or "none").encode(),
+                 top_p=a.top_p, top_k=a.top_k, decoding_attn_split_k=a.configure_decoding_attn_split_k + 1,
+                 decoding_attn_tpb=a.specify_decoding_attn_tpb)
     cfg._keep = arr
     return cfg
 
@@ -247,11 +250,25 @@ def add_flags(ap):
     ap.add_argument("--tokenizer-type", default="sentencepiece")
     ap.add_argument("--model-type", default="llama")
     ap.add_argument("--quant-method", default="none", help="none | online_i8i8 (tools/llm_server.cc:62)")
+    ap.add_argument("--top-p", type=float, default=0.0)
+    ap.add_argument("--top-k", type=int, default=1)
+    ap.add_argument("--configure-decoding-attn-split-k", type=int, default=1, help="always-on(2)/heuristic(1)/off(0)")
+    ap.add_argument("--specify-decoding-attn-tpb", type=int, default=0, help="512/256/heuristic(0)")
+    # flags of tools/llm_server.cc that have no effect on this backend: accepted so that a command line carries over unchanged
+    ap.add_argument("--model-format", default="pplhip")
+    ap.add_argument("--tokenizer-config-path", default="")
+    ap.add_argument("--special-tokens", default="")
+    ap.add_argument("--cublas-layout-hint", default="default")
+    for flag in ("--disable-decoding-shm-mha", "--disable-decoding-inf-mha", "--disable-decoding-inf-gqa", "--disable-graph-fusion",
+                 "--enable-profiling", "--enable-backtrace", "--version"):
+        ap.add_argument(flag, action="store_true")
+    ap.add_argument("--monitor-port", type=int, default=23333)
+    ap.add_argument("--control-port", type=int, default=12345)
     ap.add_argument("--synthetic-weights", action="store_true")
     ap.add_argument("--synthetic-seed", type=int, default=1234)
     ap.add_argument("--kv-cache-max-tokens", type=int, default=0)
-    ap.add_argument("--host", default="0.0.0.0")
-    ap.add_argument("--port", type=int, default=23333)
+    ap.add_argument("--host", default="127.0.0.1")            # tools/llm_server.cc:84-85
+    ap.add_argument("--port", type=int, default=10086)
 
 
 async def serve(a, ready=None):

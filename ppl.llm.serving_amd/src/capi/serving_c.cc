@@ -110,10 +110,11 @@ int pplsrv_create(const pplsrv_config* cfg, pplsrv** out) {
     rc.synthetic_weights = cfg->synthetic_weights != 0;
     rc.synthetic_seed = cfg->synthetic_seed;
     rc.kv_cache_max_tokens_override = cfg->kv_cache_max_tokens;
-    rc.engine_config.configure_decoding_attn_split_k = 1;
+    rc.engine_config.configure_decoding_attn_split_k = cfg->decoding_attn_split_k > 0 ? cfg->decoding_attn_split_k - 1 : 1;
+    rc.engine_config.specify_decoding_attn_tpb = cfg->decoding_attn_tpb;
     if (cfg->quant_method && cfg->quant_method[0]) rc.engine_config.quant_method = cfg->quant_method;
-    gc.top_p = 0.f;
-    gc.top_k = 1;
+    gc.top_p = cfg->top_p;
+    gc.top_k = cfg->top_k > 0 ? cfg->top_k : 1;
     gc.enable_penalty = rc.enable_penalty;
     gc.max_running_batch = rc.max_running_batch;
     gc.max_tokens_per_step = rc.max_tokens_per_step;

@@ -32,6 +32,10 @@ typedef struct pplsrv_config {
     const char* tokenizer_type;    /* --tokenizer-type, NULL = "sentencepiece" */
     const char* model_type;        /* --model-type, NULL = "llama" (LlamaTokenizer: BOS first) */
     const char* quant_method;      /* --quant-method: NULL / "none" / "online_i8i8" */
+    float top_p;                   /* --top-p, --top-k: the generator's defaults (GeneratorConfig; 0 / 0 = the tools' 0.0 and 1) */
+    int32_t top_k;
+    int32_t decoding_attn_split_k; /* --configure-decoding-attn-split-k + 1 (0 = the default, heuristic) */
+    int32_t decoding_attn_tpb;     /* --specify-decoding-attn-tpb */
 } pplsrv_config;
 
 /* ParseRequest of grpc_server.cc:218-252 already applied by the caller */
