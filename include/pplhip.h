@@ -289,6 +289,10 @@ PPLHIP_API int pplhip_op_linear_swiglu(void* stream, const void* x, const void* 
 /* online_i8i8 (W8A8, src/backends/cuda/resource_manager.cc:51-52).  Per-token activation quantisation: q[M,K] int8,
  * sx[M] = max|x| / 127; per-output-row weight quantisation of an fp16 [N,K] matrix: q[N,K] int8, scale[N] fp16;
  * y[m,n] = (sum_k xq * w as int32) * sx[m] * scale[n], rounded to fp16 (or kept fp32); swiglu as in pplhip_op_linear_swiglu. */
+/* (Skip)RMSNorm whose output goes straight to the int8 operand of the next linear (what the runtime launches in front of wqkv / w13
+ * in online_i8i8 mode): q[T,hidden] / sx[T] = pplhip_op_quant_act(pplhip_op_rmsnorm(...)), bit for bit */
+PPLHIP_API int pplhip_op_rmsnorm_quant(void* stream, const void* x, const void* skip, const void* w, float eps, int64_t T,
+                                       int32_t hidden, void* residual_out, void* q, float* sx);
 PPLHIP_API int pplhip_op_quant_act(void* stream, const void* x, int64_t M, int32_t K, void* q, float* sx);
 PPLHIP_API int pplhip_op_quant_weight(void* stream, const void* w, int32_t N, int32_t K, void* q, void* scale);
 PPLHIP_API int pplhip_op_linear_i8(void* stream, const void* xq, const float* sx, const void* w, const void* scale, int64_t M,

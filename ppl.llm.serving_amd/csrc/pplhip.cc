@@ -1530,6 +1530,12 @@ int pplhip_op_linear_swiglu(void* stream, const void* x, const void* w, const vo
                                false, nullptr, 0, true));
 }
 
+int pplhip_op_rmsnorm_quant(void* stream, const void* x, const void* skip, const void* w, float eps, int64_t T, int32_t hidden,
+                            void* residual_out, void* q, float* sx) {
+    return op_rc(launch_rmsnorm((hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)skip, (const uint16_t*)w, eps, T, hidden, nullptr,
+                                nullptr, (uint16_t*)residual_out, (int8_t*)q, sx));
+}
+
 int pplhip_op_quant_act(void* stream, const void* x, int64_t M, int32_t K, void* q, float* sx) {
     return op_rc(launch_quant_act((hipStream_t)stream, (const uint16_t*)x, M, K, K, (int8_t*)q, K, sx));
 }

@@ -32,6 +32,45 @@ def test_quant_act_bit_exact(M, K):
     assert (sx.cpu().numpy() == wsx).all()
 
 
+@pytest.mark.parametrize("hidden", [256, 4096, 5120, 8192])
+@pytest.mark.parametrize("skip", [False, True])
+def test_rmsnorm_with_fused_quantiser_bit_exact(hidden, skip):
+    """the norm in front of wqkv / w13 writes int8 + per-token scale directly: same bytes as rmsnorm followed by the quantiser"""
+    m = load_pplhip()
+    rng = np.random.default_rng(hidden + skip)
+    T = 37
+    x = f16(rng.standard_normal((T, hidden)) * rng.uniform(0.1, 4, size=(T, 1)))
+    sk = f16(rng.standard_normal((T, hidden))) if skip else None
+    w = f16(1 + 0.1 * rng.standard_normal(hidden))
+    xn = np.empty((T, hidden), np.float32)
+    res = np.empty((T, hidden), np.float32)
+    xs = x.astype(np.float32)
+    sks = sk.astype(np.float32) if skip else None
+    ref.lib().ref_rmsnorm(xs.ctypes.data, None if sks is None else sks.ctypes.data, w.ctypes.data, 1e-5, T, hidden, xn.ctypes.data,
+                          res.ctypes.data)
+    wq, wsx = np.empty((T, hidden), np.int8), np.empty(T, np.float32)
+    ref.lib().ref_quant_act_rows(xn.ctypes.data, T, hidden, wq.ctypes.data, wsx.ctypes.data)
+    # device: the plain norm (fp16 out) must round like the oracle for the comparison to be meaningful at all
+    out = torch.empty((T, hidden), dtype=torch.float16, device="cuda")
+    dx, dw = dev(x), dev(w)
+    dsk = dev(sk) if skip else None
+    ck(m.lib().pplhip_op_rmsnorm(None, dx.data_ptr(), dsk.data_ptr() if skip else None, dw.data_ptr(), 1e-5, T, hidden, out.data_ptr(), None))
+    q = torch.empty((T, hidden), dtype=torch.int8, device="cuda")
+    sx = torch.empty(T, dtype=torch.float32, device="cuda")
+    resd = torch.empty((T, hidden), dtype=torch.float16, device="cuda")
+    ck(m.lib().pplhip_op_rmsnorm_quant(None, dx.data_ptr(), dsk.data_ptr() if skip else None, dw.data_ptr(), 1e-5, T, hidden,
+                                       resd.data_ptr() if skip else None, q.data_ptr(), sx.data_ptr()))
+    # fused == unfused on the device, bit for bit
+    q2 = torch.empty_like(q)
+    sx2 = torch.empty_like(sx)
+    ck(m.lib().pplhip_op_quant_act(None, out.data_ptr(), T, hidden, q2.data_ptr(), sx2.data_ptr()))
+    assert (q == q2).all() and (sx == sx2).all()
+    # ... and equal to the oracle wherever the device's fp16 norm output equals the oracle's (the norm itself carries a tolerance)
+    same_rows = (out.float().cpu().numpy() == xn).all(axis=1)
+    assert same_rows.mean() > 0.5
+    assert (q.cpu().numpy()[same_rows] == wq[same_rows]).all() and (sx.cpu().numpy()[same_rows] == wsx[same_rows]).all()
+
+
 @pytest.mark.parametrize("N,K", [(48, 256), (300, 4096), (16, 1376)])
 def test_quant_weight_bit_exact(N, K):
     m = load_pplhip()
