@@ -228,6 +228,11 @@ PPLHIP_API int pplhip_set_inputs(pplhip_ctx* ctx, int rank, const pplhip_step* s
 PPLHIP_API int pplhip_run(pplhip_ctx* ctx, int rank, int cache_prefill);
 
 /* device pointer + row stride (floats) of `logits fp32[B, vocab]` of the last run (llm_engine.cc:207-222). */
+/* Diagnosis (tests bisect a logits difference per layer with it): pplhip_run with the residual stream captured after every
+ * layer in the oracle's convention: out[0] = embeddings, out[l+1] = fp16(h + FFN output of layer l), fp32 [L+1, T, hidden].
+ * Launches eagerly and synchronises the rank's stream.  Not used by any backend. */
+PPLHIP_API int pplhip_debug_run_dump(pplhip_ctx* ctx, int rank, float* hidden_dump_host);
+
 PPLHIP_API int pplhip_logits(pplhip_ctx* ctx, int rank, float** logits_device, int64_t* stride);
 
 /* test/debug: synchronises the rank's stream and copies the logits [batch, vocab] to host. */

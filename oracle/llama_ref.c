@@ -42,7 +42,17 @@
 typedef uint16_t f16;
 static inline float h2f(f16 h) { return _cvtsh_ss(h); }
 static inline f16 f2h(float f) { return _cvtss_sh(f, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC); }
-static inline float rh(float f) { return h2f(f2h(f)); } /* round through fp16 */
+/* arithmetic mode of the whole library (ref_set_mode; default 0 = the specification the device is held against):
+ *   bit 0  REF_MODE_FP32_ACT  no fp16 rounding of computed activations, an unquantised KV slab holds fp32: the ALGORITHM in
+ *                             (almost) exact arithmetic -- pinned against HuggingFace fp32 at ~1e-5 (tests/test_oracle_hf.py);
+ *                             separates "algorithm wrong" from "rounding differs"
+ *   bit 1  REF_MODE_F64_ACC   dot products accumulate in double (an exactly rounded fp32 result)
+ *   bit 2  REF_MODE_ALT_ORDER dot products in a different, equally valid fp32 summation order: oracle(mode 4) vs oracle(mode 0)
+ *                             measures how far two correct fp16 implementations of this specification drift apart
+ *                             (the noise floor the device tolerances are derived from, tests/test_gpu_fulldepth.py) */
+enum { REF_MODE_FP32_ACT = 1, REF_MODE_F64_ACC = 2, REF_MODE_ALT_ORDER = 4 };
+static int g_mode = 0;
+static inline float rh(float f) { return (g_mode & REF_MODE_FP32_ACT) ? f : h2f(f2h(f)); } /* round through fp16 */
 
 /* ------------------------------------------------------------------------------------------------
  * model description -- field-for-field the same as pplhip_model_desc (include/pplhip.h), which carries
@@ -97,7 +107,8 @@ typedef struct ref_model {
     float* rope;      /* [max_position, D]: cos[0..D/2) then sin[0..D/2) */
     /* KV slab */
     uint64_t kv_tokens;
-    void* kv_cache;   /* f16 or int8 */
+    void* kv_cache;   /* f16 (fp32 when kv_f32) or int8 */
+    int32_t kv_f32;
     f16* kv_scale;
 } ref_model;
 
@@ -240,6 +251,8 @@ static int find_tensor(ref_model* m, const char* name, void** ptr, uint64_t* byt
     return -1;
 }
 
+REF_API void ref_quant_weight_rows(const f16* w, int N, int K, int8_t* q, f16* scale);
+
 static ref_linear* find_w8_linear(ref_model* m, const char* name) {
     int l = -1; char rest[128];
     if (sscanf(name, "layers.%d.%127s", &l, rest) != 2 || l < 0 || l >= m->d.num_layers) return NULL;
@@ -322,11 +335,13 @@ static kv_strides kv_strides_of(int layout, int64_t N, int64_t L, int64_t h, int
     return s;
 }
 
+/* an unquantised slab holds fp16, or fp32 in REF_MODE_FP32_ACT (the mode in force when the slab is allocated) */
 REF_API int ref_kv_alloc(ref_model* m, uint64_t tokens) {
     free(m->kv_cache); free(m->kv_scale); m->kv_scale = NULL;
     m->kv_tokens = tokens;
     const uint64_t elems = tokens * m->d.num_layers * 2 * m->Hkv * m->D;
-    m->kv_cache = calloc(elems, m->d.cache_quant_bit == 8 ? 1 : 2);
+    m->kv_f32 = m->d.cache_quant_bit == 0 && (g_mode & REF_MODE_FP32_ACT);
+    m->kv_cache = calloc(elems, m->d.cache_quant_bit == 8 ? 1 : (m->kv_f32 ? 4 : 2));
     if (m->d.cache_quant_bit == 8) m->kv_scale = (f16*)calloc(elems / m->d.cache_quant_group, 2);
     return m->kv_cache ? 0 : -3;
 }
@@ -334,8 +349,10 @@ REF_API void* ref_kv_ptr(ref_model* m, int which) { return which ? (void*)m->kv_
 REF_API uint64_t ref_kv_bytes(ref_model* m, int which) {
     const uint64_t elems = m->kv_tokens * m->d.num_layers * 2 * m->Hkv * m->D;
     if (which) return m->d.cache_quant_bit == 8 ? elems / m->d.cache_quant_group * 2 : 0;
-    return elems * (m->d.cache_quant_bit == 8 ? 1 : 2);
+    return elems * (m->d.cache_quant_bit == 8 ? 1 : (m->kv_f32 ? 4 : 2));
 }
+REF_API void ref_set_mode(int mode) { g_mode = mode; }
+REF_API int ref_get_mode(void) { return g_mode; }
 
 /* KV slot of (request b, absolute position pos): mode 0 cache_indices[b] + pos
  * (src/generator/llm_generator.cc:487, llm_engine.cc:64-66); mode 1 page_list[b, pos/P]*P + pos%P
@@ -377,6 +394,29 @@ REF_API void ref_rmsnorm(const float* x, const float* skip, const f16* w, float 
 }
 
 static inline float dot_f32(const float* a, const float* b, int n) {
+    if (g_mode & REF_MODE_F64_ACC) {
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        int k = 0;
+        for (; k + 4 <= n; k += 4) {
+            s0 += (double)a[k] * b[k]; s1 += (double)a[k + 1] * b[k + 1];
+            s2 += (double)a[k + 2] * b[k + 2]; s3 += (double)a[k + 3] * b[k + 3];
+        }
+        for (; k < n; ++k) s0 += (double)a[k] * b[k];
+        return (float)((s0 + s1) + (s2 + s3));
+    }
+    if (g_mode & REF_MODE_ALT_ORDER) { /* two 8-lane accumulators over 16-element steps, lanes summed left to right */
+        __m256 c0 = _mm256_setzero_ps(), c1 = _mm256_setzero_ps();
+        int k = 0;
+        for (; k + 16 <= n; k += 16) {
+            c0 = _mm256_fmadd_ps(_mm256_loadu_ps(a + k), _mm256_loadu_ps(b + k), c0);
+            c1 = _mm256_fmadd_ps(_mm256_loadu_ps(a + k + 8), _mm256_loadu_ps(b + k + 8), c1);
+        }
+        float t[8]; _mm256_storeu_ps(t, _mm256_add_ps(c0, c1));
+        float s = 0;
+        for (int i = 0; i < 8; ++i) s += t[i];
+        for (; k < n; ++k) s += a[k] * b[k];
+        return s;
+    }
     __m256 acc0 = _mm256_setzero_ps(), acc1 = _mm256_setzero_ps(), acc2 = _mm256_setzero_ps(), acc3 = _mm256_setzero_ps();
     int k = 0;
     for (; k + 32 <= n; k += 32) {
@@ -560,7 +600,8 @@ REF_API void ref_rope_kv_write(float* qkv, const float* rope, const ref_model_de
                     const float* x = r + (int64_t)(H + kv * Hkv + h) * D;
                     const int64_t base = layer * cs.sL + kv * cs.sKV + h * cs.sH + slot * cs.sN;
                     if (d->cache_quant_bit == 0) {
-                        for (int i = 0; i < D; ++i) ((f16*)kv_cache)[base + i] = f2h(x[i]);
+                        if (g_mode & REF_MODE_FP32_ACT) for (int i = 0; i < D; ++i) ((float*)kv_cache)[base + i] = x[i];
+                        else for (int i = 0; i < D; ++i) ((f16*)kv_cache)[base + i] = f2h(x[i]);
                     } else {
                         const int64_t sbase = layer * ss.sL + kv * ss.sKV + h * ss.sH + slot * ss.sN;
                         for (int gi = 0; gi < D / g; ++gi) {
@@ -591,6 +632,7 @@ REF_API void ref_attention(const float* qkv, const ref_model_desc* d, int H, int
     const int64_t row = (int64_t)(H + 2 * Hkv) * D;
     const int g = d->cache_quant_group;
     const int grp = H / Hkv;
+    const int f32kv = d->cache_quant_bit == 0 && (g_mode & REF_MODE_FP32_ACT);
     const float sm = 1.0f / sqrtf((float)D);
     const kv_strides cs = kv_strides_of(d->cache_layout, kv_tokens, d->num_layers, Hkv, D);
     const kv_strides ss = kv_strides_of(d->cache_layout, kv_tokens, d->num_layers, Hkv, D / (g > 0 ? g : 1));
@@ -610,7 +652,10 @@ REF_API void ref_attention(const float* qkv, const ref_model_desc* d, int H, int
                 for (int64_t j = 0; j <= pos; ++j) {
                     const int64_t slot = kv_slot(d, cache_indices, max_pages, b, j);
                     const int64_t base = layer * cs.sL + 0 * cs.sKV + hk * cs.sH + slot * cs.sN;
-                    if (d->cache_quant_bit == 0) for (int i = 0; i < D; ++i) vec[i] = h2f(((const f16*)kv_cache)[base + i]);
+                    if (d->cache_quant_bit == 0) {
+                        if (f32kv) for (int i = 0; i < D; ++i) vec[i] = ((const float*)kv_cache)[base + i];
+                        else for (int i = 0; i < D; ++i) vec[i] = h2f(((const f16*)kv_cache)[base + i]);
+                    }
                     else {
                         const int64_t sbase = layer * ss.sL + 0 * ss.sKV + hk * ss.sH + slot * ss.sN;
                         for (int i = 0; i < D; ++i) vec[i] = (float)((const int8_t*)kv_cache)[base + i] * h2f(kv_scale[sbase + i / g]);
@@ -624,7 +669,10 @@ REF_API void ref_attention(const float* qkv, const ref_model_desc* d, int H, int
                     den += p;
                     const int64_t slot = kv_slot(d, cache_indices, max_pages, b, j);
                     const int64_t base = layer * cs.sL + 1 * cs.sKV + hk * cs.sH + slot * cs.sN;
-                    if (d->cache_quant_bit == 0) for (int i = 0; i < D; ++i) acc[i] += (double)p * h2f(((const f16*)kv_cache)[base + i]);
+                    if (d->cache_quant_bit == 0) {
+                        if (f32kv) for (int i = 0; i < D; ++i) acc[i] += (double)p * ((const float*)kv_cache)[base + i];
+                        else for (int i = 0; i < D; ++i) acc[i] += (double)p * h2f(((const f16*)kv_cache)[base + i]);
+                    }
                     else {
                         const int64_t sbase = layer * ss.sL + 1 * ss.sKV + hk * ss.sH + slot * ss.sN;
                         for (int i = 0; i < D; ++i)

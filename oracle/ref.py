@@ -123,8 +123,29 @@ def lib():
                                  C.c_float, C.c_void_p, C.c_void_p]
         L.ref_penalty.argtypes = [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_void_p]
         L.ref_num_threads.restype = C.c_int
+        L.ref_set_mode.argtypes = [C.c_int]
         _LIB = L
     return _LIB
+
+
+MODE_FP16, MODE_FP32_ACT, MODE_F64_ACC, MODE_ALT_ORDER = 0, 1, 2, 4
+
+
+class mode:
+    """`with ref.mode(ref.MODE_FP32_ACT | ref.MODE_F64_ACC): ...` -- the oracle's arithmetic mode (llama_ref.c, g_mode) for the
+    models CREATED and run inside the block (an unquantised KV slab allocated in fp32 mode holds fp32).  Mode 0 is the
+    specification the device is compared with; the others exist to pin the algorithm (fp32 activations vs HuggingFace) and to
+    measure the noise floor of the fp16 specification (alternative summation order)."""
+
+    def __init__(self, m):
+        self.m = m
+
+    def __enter__(self):
+        self.old = lib().ref_get_mode()
+        lib().ref_set_mode(self.m)
+
+    def __exit__(self, *a):
+        lib().ref_set_mode(self.old)
 
 
 def _p(a):
@@ -178,7 +199,13 @@ class RefModel:
             return None
         buf = (C.c_uint8 * n).from_address(lib().ref_kv_ptr(self.h, which))
         dt = np.float16 if which == 1 or self.desc.cache_quant_bit == 0 else np.int8
+        if which == 0 and self.desc.cache_quant_bit == 0 and n == self.kv_tokens_elems() * 4:
+            dt = np.float32                                            # slab allocated in MODE_FP32_ACT
         return np.frombuffer(buf, dtype=dt)
+
+    def kv_tokens_elems(self):
+        d = self.desc
+        return self.kv_tokens * d.num_layers * 2 * (d.num_kv_heads // self.tp_size) * (d.hidden_dim // d.num_heads)
 
 
 def tensor_names(desc):

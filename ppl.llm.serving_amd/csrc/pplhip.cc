@@ -119,6 +119,9 @@ struct Rank {
     uint32_t* p2p_status = nullptr;     // pinned host word a kernel raises when one of its bounded spins timed out
     int32_t* d_flag = nullptr;          // one int for the cross-process agreement on the self-test
 
+    // diagnosis (pplhip_debug_run_dump): residual stream h and the pending row-parallel FFN output after every layer
+    uint16_t* dump_dev = nullptr;  // [L+1][2][T, hidden] fp16 (slot 0 = h, slot 1 = pending), allocated for one run
+
     // profiling
     std::vector<ProfEvent> prof;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_free;
@@ -175,6 +178,9 @@ int fail(pplhip_ctx* c, int rank, int code, const std::string& msg) {
         if (e__ != ncclSuccess)                                                                                      \
             return fail(c, r, PPLHIP_DEVICE_RUNTIME_ERROR, std::string(#expr) + ": " + ncclGetErrorString(e__));     \
     } while (0)
+
+static inline float h2f_host(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+static inline uint16_t f2h_host(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
 
 // k-tile the padded row stride of w2 / the SwiGLU output is rounded to: 64 (fp16-activation tile GEMM), 128 (int8 x int8)
 static int k_tile(const pplhip_model_desc& d) { return d.act_quant_bit == 8 ? 128 : 64; }
@@ -1245,6 +1251,8 @@ static int run_launches(pplhip_ctx* c, int rank) {
     HIPCK(c, rank, launch_embedding(s, R.d_tok, R.embed, T, hd, R.h));
     const uint16_t* pending = nullptr;
     int rc;
+    const size_t dump_n = (size_t)T * hd;  // elements of one dumped matrix
+    if (R.dump_dev) HIPCK(c, rank, hipMemcpyAsync(R.dump_dev, R.h, dump_n * 2, hipMemcpyDeviceToDevice, s));
     for (int l = 0; l < d.num_layers; ++l) {
         for (int i = 0; i < nck; ++i) {
             if (ov && l > 0 && !tpdbg2) HIPCK(c, rank, hipStreamWaitEvent(s, R.ev_comm[i], 0));  // part2 rows of chunk i are reduced
@@ -1257,6 +1265,11 @@ static int run_launches(pplhip_ctx* c, int rank) {
             if (comm && (rc = chunk_allreduce(c, rank, R.part2, ck[i], i, ov))) return rc;
         }
         pending = R.part2;
+        if (R.dump_dev) {
+            if (ov && !tpdbg2) for (int i = 0; i < nck; ++i) HIPCK(c, rank, hipStreamWaitEvent(s, R.ev_comm[i], 0));
+            HIPCK(c, rank, hipMemcpyAsync(R.dump_dev + (size_t)(l + 1) * 2 * dump_n, R.h, dump_n * 2, hipMemcpyDeviceToDevice, s));
+            HIPCK(c, rank, hipMemcpyAsync(R.dump_dev + ((size_t)(l + 1) * 2 + 1) * dump_n, R.part2, dump_n * 2, hipMemcpyDeviceToDevice, s));
+        }
     }
     if (ov && !tpdbg2) for (int i = 0; i < nck; ++i) HIPCK(c, rank, hipStreamWaitEvent(s, R.ev_comm[i], 0));
     // K11: last-token gather + final (Skip)RMSNorm (the last FFN output is folded into the residual of the gathered
@@ -1352,6 +1365,36 @@ int pplhip_run(pplhip_ctx* c, int rank, int cache_prefill) {
     bool done = false;
     if (int rc = run_decode_graph(c, rank, &done)) return rc;
     return done ? 0 : run_launches(c, rank);
+}
+
+// Diagnosis entry point (tests bisect a logits difference per layer with it): pplhip_run with the residual stream captured after
+// every layer, in the oracle's hidden_dump convention (oracle/llama_ref.c ref_forward): out[0] = embeddings, out[l + 1] =
+// fp16(h + row-parallel FFN output of layer l) as fp32, [L + 1, T, hidden].  Eager launches, synchronises.
+int pplhip_debug_run_dump(pplhip_ctx* c, int rank, float* hidden_dump_host) {
+    if (!c || rank < 0 || rank >= (int)c->ranks.size() || !hidden_dump_host) return PPLHIP_INVALID_VALUE;
+    Rank& R = c->ranks[rank];
+    if (!R.kv_cache) return fail(c, rank, PPLHIP_INVALID_VALUE, "kv slab not allocated");
+    HIPCK(c, rank, hipSetDevice(R.device));
+    if (R.B == 0) return 0;
+    const int L = c->d.num_layers;
+    const size_t n = (size_t)R.T * c->d.hidden_dim;
+    HIPCK(c, rank, hipMalloc((void**)&R.dump_dev, (size_t)(L + 1) * 2 * n * 2));
+    int rc = run_launches(c, rank);
+    std::vector<uint16_t> host((size_t)(L + 1) * 2 * n);
+    hipError_t e = hipStreamSynchronize(R.stream);
+    if (e == hipSuccess) e = hipMemcpy(host.data(), R.dump_dev, host.size() * 2, hipMemcpyDeviceToHost);
+    hipFree(R.dump_dev);
+    R.dump_dev = nullptr;
+    if (rc) return rc;
+    HIPCK(c, rank, e);
+    for (size_t i = 0; i < n; ++i) hidden_dump_host[i] = h2f_host(host[i]);
+    for (int l = 1; l <= L; ++l) {
+        const uint16_t* a = host.data() + (size_t)l * 2 * n;
+        const uint16_t* b = a + n;
+        float* o = hidden_dump_host + (size_t)l * n;
+        for (size_t i = 0; i < n; ++i) o[i] = h2f_host(f2h_host(h2f_host(a[i]) + h2f_host(b[i])));
+    }
+    return p2p_check(c, rank);
 }
 
 int pplhip_logits(pplhip_ctx* c, int rank, float** logits_device, int64_t* stride) {

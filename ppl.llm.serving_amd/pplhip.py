@@ -75,7 +75,7 @@ SYMBOLS = [
     "pplhip_comm_export", "pplhip_comm_connect", "pplhip_comm_mode",
     "pplhip_last_error", "pplhip_rank_load", "pplhip_rank_set_tensor", "pplhip_rank_init_synthetic",
     "pplhip_kv_block_bytes", "pplhip_kv_capacity", "pplhip_kv_alloc", "pplhip_kv_ptrs", "pplhip_kv_read",
-    "pplhip_kv_write", "pplhip_kv_fill_synthetic", "pplhip_set_inputs", "pplhip_run", "pplhip_logits", "pplhip_copy_logits", "pplhip_sync",
+    "pplhip_kv_write", "pplhip_kv_fill_synthetic", "pplhip_set_inputs", "pplhip_run", "pplhip_debug_run_dump", "pplhip_logits", "pplhip_copy_logits", "pplhip_sync",
     "pplhip_sample", "pplhip_penalty", "pplhip_profile_reset", "pplhip_profile_get", "pplhip_mem_info",
     "pplhip_op_embedding", "pplhip_op_rmsnorm", "pplhip_op_linear", "pplhip_op_linear_swiglu", "pplhip_op_rmsnorm_quant", "pplhip_op_quant_act", "pplhip_op_quant_weight",
     "pplhip_op_linear_i8", "pplhip_op_silu_mul", "pplhip_op_rope_kv_write",
@@ -115,6 +115,7 @@ def lib():
         L.pplhip_kv_fill_synthetic.argtypes = [vp, C.c_int, u64]
         L.pplhip_set_inputs.argtypes = [vp, C.c_int, C.POINTER(Step)]
         L.pplhip_run.argtypes = [vp, C.c_int, C.c_int]
+        L.pplhip_debug_run_dump.argtypes = [vp, C.c_int, vp]
         L.pplhip_logits.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(i64)]
         L.pplhip_copy_logits.argtypes = [vp, C.c_int, vp, i64]
         L.pplhip_sync.argtypes = [vp, C.c_int]
@@ -288,6 +289,12 @@ class Context:
 
     def run(self, rank, cache_prefill=0):
         self._ck(lib().pplhip_run(self.h, rank, cache_prefill), rank, "run")
+
+    def run_dump(self, rank, num_tokens):
+        """diagnosis: run the step and return the residual stream after every layer, fp32 [L+1, T, hidden] (oracle convention)"""
+        out = np.empty((self.desc.num_layers + 1, num_tokens, self.desc.hidden_dim), dtype=np.float32)
+        self._ck(lib().pplhip_debug_run_dump(self.h, rank, out.ctypes.data), rank, "debug_run_dump")
+        return out
 
     def sync(self, rank=0):
         self._ck(lib().pplhip_sync(self.h, rank), rank, "sync")

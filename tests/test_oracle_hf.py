@@ -70,16 +70,71 @@ def test_oracle_matches_hf(golden_dir, name, layout, mode):
     max_tokens = 256
     m.kv_alloc(max_tokens)
     logits, tokens = run_generation([m], prompts, steps, desc, max_tokens)
-    # the oracle rounds activations to fp16 like the device path; HF runs in fp32
+    # the oracle rounds activations to fp16 like the device path; HF runs in fp32: what is left is fp16 rounding noise
+    # (observed 0.7e-3 mha / 1.6e-3 gqa).  The ALGORITHM is pinned two orders tighter in test_oracle_fp32_mode_matches_hf.
     err = np.abs(logits - hf_logits).max()
     scale = np.abs(hf_logits).max()
-    assert err < 2e-2 * max(1.0, scale), (err, scale)
+    assert err < 3e-3 * max(1.0, scale), (err, scale)
     # greedy tokens must agree wherever HF's top-2 margin is not within the rounding noise
     srt = np.sort(hf_logits, -1)
     margin = srt[..., -1] - srt[..., -2]
     safe = margin > 4 * err
     assert safe.mean() > 0.8
     assert (tokens[safe] == hf_tokens[safe]).all()
+
+
+@pytest.mark.parametrize("name", ["mha", "gqa"])
+@pytest.mark.parametrize("layout,mode", [(3, 0), (1, 1)])
+def test_oracle_fp32_mode_matches_hf(golden_dir, name, layout, mode):
+    """with the fp16 roundings switched off (ref.MODE_FP32_ACT: fp32 activations, fp32 KV slab) the oracle IS
+    the HuggingFace computation up to fp32 summation order: logits within 1e-5 (observed 0.5e-6 / 1.3e-6), every greedy token
+    equal.  This pins the algorithm -- RoPE pairing, GQA head mapping, norm placement, SwiGLU, packing, paging -- separately
+    from the rounding of the fp16 mode the device is compared with."""
+    meta, weights, prompts, hf_logits, hf_tokens, hidden0 = load_fixture(os.path.join(golden_dir, f"hf_tiny_{name}.npz"))
+    for md in (ref.MODE_FP32_ACT, ref.MODE_FP32_ACT | ref.MODE_F64_ACC):
+        with ref.mode(md):
+            desc = desc_from_meta(meta, cache_layout=layout, cache_mode=mode, page_size=4 if mode else 0)
+            m = ref.RefModel(desc)
+            for k, v in weights.items():
+                m.set_tensor(k, v)
+            m.kv_alloc(256)
+            logits, tokens = run_generation([m], prompts, hf_logits.shape[1], desc, 256)
+            if name == "mha":
+                p = prompts[0]
+                m2 = ref.RefModel(desc)
+                for k, v in weights.items():
+                    m2.set_tensor(k, v)
+                m2.kv_alloc(256)
+                _, dump = ref.forward([m2], ref.make_step(p, [0, len(p)], [0], np.arange(64, dtype=np.int64)[None, :] if mode else [0], 0,
+                                                          max_pages=64 if mode else 0), dump_hidden=True)
+                for l in range(hidden0.shape[0]):
+                    assert np.abs(dump[l] - hidden0[l]).max() <= 1e-5 * max(1.0, np.abs(hidden0[l]).max()), l
+                m2.close()
+            m.close()
+        assert np.abs(logits - hf_logits).max() <= 1e-5 * max(1.0, np.abs(hf_logits).max())
+        assert (tokens == hf_tokens).all()
+    assert ref.lib().ref_get_mode() == 0
+
+
+def test_alternative_summation_order_is_the_same_specification(golden_dir):
+    """ref.MODE_ALT_ORDER only changes the order fp32 dot products are summed in: against HF it is as close as mode 0, and
+    the two fp16 oracles differ from each other by fp16 rounding noise (the noise floor tests/test_gpu_fulldepth.py measures
+    at full depth on the GPU box)."""
+    meta, weights, prompts, hf_logits, hf_tokens, _ = load_fixture(os.path.join(golden_dir, "hf_tiny_gqa.npz"))
+    out = {}
+    for md in (ref.MODE_FP16, ref.MODE_ALT_ORDER):
+        with ref.mode(md):
+            desc = desc_from_meta(meta)
+            m = ref.RefModel(desc)
+            for k, v in weights.items():
+                m.set_tensor(k, v)
+            m.kv_alloc(256)
+            out[md], _ = run_generation([m], prompts, hf_logits.shape[1], desc, 256)
+            m.close()
+    scale = max(1.0, np.abs(hf_logits).max())
+    assert np.abs(out[4] - hf_logits).max() < 3e-3 * scale
+    d = np.abs(out[4] - out[0]).max() / scale
+    assert 0 < d < 3e-3, d
 
 
 def test_oracle_residual_stream_matches_hf(golden_dir):
