@@ -269,6 +269,8 @@ def main():
     ap.add_argument("--no-paced-leg", action="store_true", help="serving leg: skip the second run at 64 requests/s")
     ap.add_argument("--breakdown", action="store_true",
                     help="also time the GEMM launches (events around every kernel class: costs the step ~3 %%; default: decode attention only)")
+    ap.add_argument("--breakdown-steps", type=int, default=4,
+                    help="extra, untimed decode steps with every kernel class bracketed, for breakdown_ms_per_step.gemm (0: skip)")
     ap.add_argument("--no-i8i8-leg", action="store_true",
                     help="skip the secondary run of the same decode step in the reference's other int8 mode (--quant-method online_i8i8)")
     ap.add_argument("--ragged-steps", type=int, default=4, help="decode steps at a samples_1024-shaped ragged kv_len batch (0: skip)")
@@ -310,7 +312,7 @@ def main():
     if args.layers:
         mk["num_layers"] = args.layers
     B, K, W = args.batch, args.steps, args.warmup
-    total_len = args.kv_len + K + W + 2
+    total_len = args.kv_len + K + W + 2 + (0 if args.breakdown else args.breakdown_steps)
     desc = P.make_desc(max_position=max(2048, total_len + 1), cache_quant_bit=args.kv_quant,
                        cache_quant_group=8 if args.kv_quant else 1, cache_layout=3, cache_mode=args.cache_mode,
                        page_size=16 if args.cache_mode else 0,
@@ -401,20 +403,41 @@ def main():
     kv_sum = sum(B * (args.kv_len + i + 1) for i in range(W, W + K))  # keys read per layer over the timed steps
     bytes_total = attn_bytes_per_launch(B * K, kv_sum, H, Hkv, D, args.kv_quant) * desc.num_layers
     achieved = bytes_total / (ms_attn * 1e-3) / 1e9 if ms_attn > 0 else 0.0
-    # HBM bytes per launch from the PMC counters: collected OFFLINE by profiles/collect_r02.sh on this very command line
-    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes) and stored with the kv range and the kernel revision it
-    # was taken at; reported only when it matches what this run launched
+    # HBM bytes per launch from the PMC counters: collected OFFLINE on this very script (profiles/collect_r03.sh: rocprofv3 --pmc
+    # FETCH_SIZE / WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes) and stored PER KV LENGTH (every
+    # step of a run launches the kernel at one kv length, 32 layers each); reported when the table covers every kv length of the
+    # timed steps for the same batch / KV format / cache mode, whatever --steps / --warmup were -- never borrowed otherwise
     traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "attn_decode_traffic.json")
     if os.path.exists(tpath) and tp == 1:
         try:
             tj = json.load(open(tpath))
-            same = (tj.get("batch") == B and tj.get("kv_len_first") == args.kv_len + W + 1 and tj.get("kv_len_last") == args.kv_len + W + K
-                    and tj.get("kv_quant") == args.kv_quant and tj.get("cache_mode") == args.cache_mode)
-            traffic = tj.get("hbm_bytes_per_launch") if same else None
-            traffic_source = tj.get("source_short", "profiles/attn_decode_traffic.json") + ("" if same else " -- NOT for this launch shape, omitted")
+            table = tj.get("hbm_bytes_per_launch_by_kv_len", {})
+            want_kv = [str(args.kv_len + i + 1) for i in range(W, W + K)]
+            same = (tj.get("batch") == B and tj.get("kv_quant") == args.kv_quant and tj.get("cache_mode") == args.cache_mode
+                    and tj.get("model") == args.model and all(k in table for k in want_kv))
+            if same:
+                traffic = int(sum(table[k] for k in want_kv) / len(want_kv))
+            traffic_source = tj.get("source_short", "profiles/attn_decode_traffic.json") + ("" if same else " -- does not cover this launch shape, omitted")
         except Exception:
             traffic = None
+
+    # GEMM share of the step: 4 more decode steps, NOT part of the timed region, with every kernel class bracketed by events
+    # (an event record is a barrier packet: bracketing inside the timed region would cost it ~3 %)
+    gemm_ms_per_step, gemm_note = None, None
+    if args.breakdown:
+        gemm_ms_per_step, gemm_note = ms_gemm / K, "events around every kernel class inside the timed region (--breakdown)"
+    elif args.breakdown_steps > 0:
+        ctx.profile_mode(1)
+        ctx.profile_reset(0)
+        for i in range(W + K, W + K + args.breakdown_steps):
+            tok = step(i, tok)
+        barrier()
+        n_g, ms_g = ctx.profile_get(P.PROF_GEMM)
+        gemm_ms_per_step = ms_g / args.breakdown_steps
+        gemm_note = f"GEMM: {args.breakdown_steps} extra steps after the timed region with events around every kernel class ({n_g} launches)"
+        ctx.profile_mode(2)
+        ctx.profile_reset(0)
 
     # ragged leg: the same batch size at a samples_1024-shaped spread of context lengths (4 .. 1024 in ONE step)
     ragged = None
@@ -487,9 +510,8 @@ def main():
                          "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "launches": n_attn, "avg_launch_ms": round(ms_attn / max(n_attn, 1), 4),
                          "algorithmic_bytes_per_launch": int(bytes_total / max(n_attn, 1))},
-            "breakdown_ms_per_step": {"attn_decode": round(ms_attn / K, 3), "gemm": round(ms_gemm / K, 3) if args.breakdown else None,
-                                      "run_total_gpu": round(ms_run / K, 3),
-                                      "note": None if args.breakdown else "GEMM launches not bracketed (--breakdown does, at ~3 % of the step)"},
+            "breakdown_ms_per_step": {"attn_decode": round(ms_attn / K, 3), "gemm": round(gemm_ms_per_step, 3) if gemm_ms_per_step is not None else None,
+                                      "run_total_gpu": round(ms_run / K, 3), "note": gemm_note},
         }
         res.update(extra)
         if ragged is not None:

@@ -266,6 +266,11 @@ PPLHIP_API int pplhip_profile_reset(pplhip_ctx* ctx, int rank);
 /* synchronises, then returns number of launches and summed duration (ms) of a kernel class since reset. */
 PPLHIP_API int pplhip_profile_get(pplhip_ctx* ctx, int rank, int kernel_class, int64_t* launches, double* total_ms);
 
+/* changes opts.enable_profiling (0, 1, 2) for the steps that follow: bench.py times its steps in mode 2 (decode attention
+ * through its own dispatch packet, no barrier packets on the stream) and then brackets every kernel class on a few extra,
+ * untimed steps to report the GEMM share. */
+PPLHIP_API int pplhip_profile_mode(pplhip_ctx* ctx, int mode);
+
 /* free / total device memory of the rank's device (cudaMemGetInfo in llm_generator.cc:777). */
 PPLHIP_API int pplhip_mem_info(pplhip_ctx* ctx, int rank, uint64_t* free_bytes, uint64_t* total_bytes);
 

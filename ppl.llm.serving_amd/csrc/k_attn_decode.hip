@@ -90,12 +90,9 @@ hipError_t launch_attn_decode(hipStream_t s, const uint16_t* qkv, const KvAddr& 
     if (split < 1) split = 1;
     // grouped-query models: the MFMA kernel (k_attn_prefill.hip) reads each KV row once for the whole head group
     static const bool no_gqa = getenv("PPLHIP_ATTN_NOGQA") != nullptr;
-    const int grp = H / Hkv;
-    if (grp >= 4 && grp <= 16 && !no_gqa) {
-        if (t0 && t1) (void)hipEventRecord(t0, s);
+    if (attn_decode_gqa_supported(quant_bit, H, Hkv, D) && !no_gqa) {
         hipError_t e = launch_attn_decode_gqa(s, qkv, kv, quant_bit, seq_starts, start_pos, cache_indices, max_pages, nb, H,
-                                              Hkv, D, split, workspace, out);
-        if (t0 && t1) (void)hipEventRecord(t1, s);
+                                              Hkv, D, split, workspace, out, t0, t1);
         if (e != hipSuccess || split == 1) return e;
         const dim3 rg((unsigned)(nb * H)), rb(D < 64 ? 64 : D);
         if (D == 128) hipLaunchKernelGGL((attn_decode_reduce_kernel<128>), rg, rb, 0, s, workspace, split, out);

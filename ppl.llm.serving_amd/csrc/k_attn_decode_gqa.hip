@@ -1,0 +1,369 @@
+// K8, grouped-query variant (4 <= H / Hkv <= 16, e.g. LLaMA-2-70B: 8 query heads per KV head).  The VALU decode kernel
+// (k_attn_decode.hip) would read every KV row once per query head -- 8x the bytes -- so decode rows of grouped-query models
+// run on the matrix cores with the head group as the MFMA's second dimension: every KV byte is read from HBM ONCE.
+//
+// Round 3 rewrite.  HBM-bound kernel, so the matrix cores and the VALU have time to spare -- spent on two things:
+//   * precision: the round-2 kernel rounded the dequantised K / V (int8 x fp16 scale: 19 significant bits) and the
+//     probabilities to fp16 for the MFMAs and landed 4e-3 from the oracle at kv 2048 (70B / TP8 geometry), six times the
+//     oracle's own summation-order noise.  Now every MFMA operand is an exact hi + lo pair of fp16 numbers:
+//       K, V : hi = fp16(q * s) (packed multiply), lo = fma(q, s, -hi) -- the error term of a floating-point product is itself
+//              exactly representable (TwoProduct), so hi + lo == q * s exactly, for 1.5 packed VALU ops per element;
+//       P    : hi = fp16(p), lo = fp16(p - hi) (22 significant bits);
+//     S = Q.(Khi + Klo)  (two MFMAs per k-step), O += (Phi + Plo).(Vhi + Vlo).  The P.V MFMA contracts over 32 k-slots but
+//     a wave's sub-tile has only 16 keys, so the lo terms ride in the k-slots that used to be zero: A = (Phi | Plo),
+//     B = (Vhi | Vhi) gives Phi.Vhi + Plo.Vhi in ONE instruction; int8 KV adds A = (Phi | Plo), B = (Vlo | Vlo).
+//     fp32 accumulation throughout: what is left against the oracle is summation order.
+//   * no workgroup barriers in the streaming loop: a wave owns whole 16-key sub-tiles (keys tbeg + 16 (8 t + wave)), loads K
+//     STRAIGHT from HBM into the MFMA A-operand layout (lane = (key, quarter) takes 16-byte pieces quarter, quarter + 4, ...; the
+//     matching permutation of the contraction index is applied to the Q fragments), and passes V through a wave-PRIVATE LDS
+//     region only to transpose it (ds_read_b64_tr_b16).  GQ_NBUF sub-tiles are in flight per wave in a statically rotating set of register
+//     buffers; the 8 waves of a block meet once, to merge their online-softmax states.
+// Grid (Hkv, requests, splits); workspace / reduce kernel shared with the multi-head kernel (k_attn_decode.hip).
+// Oracle: ref_attention (oracle/llama_ref.c).
+#include <type_traits>
+#include <hip/hip_ext.h>
+#include "kernels.h"
+
+namespace pplhip {
+
+namespace {
+
+#ifndef GQ_THREADS_N
+#define GQ_THREADS_N 512
+#endif
+constexpr int GQ_THREADS = GQ_THREADS_N;
+constexpr int GQ_WAVES = GQ_THREADS / 64;
+#ifndef GQ_NBUF
+#define GQ_NBUF 2   // measured 2 / 3 / 4: 4.46 / 4.07 / 4.16 TB/s at B 256, kv 2048 (the kernel is issue-bound, not latency-bound): 16-key sub-tiles in flight per wave (register buffers, statically rotated)
+#endif
+constexpr int GQ_VSUB = 272;  // halfs per [16 keys][16 channels] V sub-tile in LDS: 256 + 16 of skew (bank spread of the writes)
+
+typedef short gq_s4 __attribute__((__vector_size__(4 * sizeof(short))));
+// transposing LDS read of a row-major [16 keys][16 channels] fp16 sub-tile: lane (channel l15, quarter kq) receives keys
+// kq*4 .. kq*4+3 of channel l15 (lane semantics pinned by profiles/probes/lds_tr_read_probe.hip)
+__device__ __forceinline__ uint2 gq_v_frag(const uint16_t* sub, int kq, int l15) {
+    const uint16_t* p = sub + (kq * 4 + (l15 >> 2)) * 16 + (l15 & 3) * 4;
+    const gq_s4 w = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gq_s4*)p);
+    return __builtin_bit_cast(uint2, w);
+}
+
+__device__ __forceinline__ h8 splat8(_Float16 v) { return h8{v, v, v, v, v, v, v, v}; }
+
+// exact product q * s of 8 small integers (fp16-exact) and an fp16 scale as hi + lo
+__device__ __forceinline__ void two_product(h8 q, _Float16 s, h8& hi, h8& lo) {
+    const h8 sv = splat8(s);
+    hi = q * sv;
+    lo = __builtin_elementwise_fma(q, sv, -hi);
+}
+
+template <int QBIT, int D, int MODE>
+__global__ __launch_bounds__(GQ_THREADS) void attn_decode_gqa_kernel(const uint16_t* __restrict__ qkv, KvAddr kv,
+                                                                     const int64_t* __restrict__ seq_starts,
+                                                                     const int64_t* __restrict__ start_pos,
+                                                                     const int64_t* __restrict__ cache_indices,
+                                                                     int64_t max_pages, int H, int Hkv, int split,
+                                                                     float* __restrict__ workspace, uint16_t* __restrict__ out) {
+    constexpr int ELT = QBIT == 8 ? 1 : 2;
+    constexpr int CH = 16 / ELT;        // channels in one 16-byte piece
+    constexpr int LPT = D / CH;         // pieces per row
+    constexpr int PPL = LPT / 4;        // pieces per lane and 16-key sub-tile (K and V alike)
+    constexpr int KSTEPS = D / 32;
+    constexpr int DT = D / 16;
+    constexpr int NIMG = QBIT == 8 ? 2 : 1;           // V images in LDS: hi (+ lo)
+    constexpr int VW = DT * GQ_VSUB;                  // halfs of one image of one wave's 16-key sub-tile
+    static_assert(LPT % 4 == 0, "a row must hold a multiple of four 16-byte pieces");
+    constexpr int V_BYTES = GQ_WAVES * NIMG * VW * 2, MERGE_BYTES = GQ_WAVES * 16 * (D + 2) * 4;
+    __shared__ __attribute__((aligned(16))) char smem[V_BYTES > MERGE_BYTES ? V_BYTES : MERGE_BYTES];
+
+    const int hk = blockIdx.x;
+    const int64_t b = blockIdx.y;
+    const int sp_i = blockIdx.z;
+    const int grp = H / Hkv;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index in an SGPR
+    const int l15 = lane & 15, kq = lane >> 4;
+    uint16_t* const vw = reinterpret_cast<uint16_t*>(smem) + wave * NIMG * VW;  // this wave's private V image(s)
+    const int64_t rowstride = (int64_t)(H + 2 * Hkv) * D;
+    const int64_t kv_len = start_pos[b] + 1;
+    const int64_t per = ((kv_len + split - 1) / split + 127) / 128 * 128;  // whole 128-key strips per split
+    const int64_t tbeg = sp_i * per;
+    const int64_t tend = (tbeg + per < kv_len) ? tbeg + per : kv_len;
+
+    // Q fragments (MFMA B operand): lane (n = head l15 of the group, kq), k-slots of step ks = the 8 channels the K fragment of
+    // the same (ks, kq) holds: int8 piece p = kq + 4 (ks / 2) -> channels 16 p + 8 (ks % 2); fp16 piece p = kq + 4 ks -> 8 p
+    h8 qf[KSTEPS];
+    {
+        const uint16_t* qrow = qkv + seq_starts[b] * rowstride + (int64_t)(hk * grp + (l15 < grp ? l15 : 0)) * D;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int ch = QBIT == 8 ? 16 * (kq + 4 * (ks >> 1)) + 8 * (ks & 1) : 8 * (kq + 4 * ks);
+            const uint4 v = *reinterpret_cast<const uint4*>(qrow + ch);
+            qf[ks] = __builtin_bit_cast(h8, l15 < grp ? v : make_uint4(0, 0, 0, 0));
+        }
+    }
+    f4 o[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[i] = f4{0.f, 0.f, 0.f, 0.f};
+    float m = -1e30f, l = 0.f;
+    const float sm_scale = 1.0f / sqrtf((float)D);
+
+    const int64_t slot0 = MODE == 0 ? cache_indices[b] : 0;
+    const char* kbase = reinterpret_cast<const char*>(kv.cache) + (int64_t)hk * kv.sH * ELT;
+    const char* vbase = kbase + kv.sKV * ELT;
+    const uint16_t* ksbase = kv.scale + (int64_t)hk * kv.ssH;
+    const uint16_t* vsbase = ksbase + kv.ssKV;
+
+    // V staging item j of this lane: (key, piece) = divmod(lane + 64 j, LPT): a load instruction covers whole rows
+    constexpr int NBUF = GQ_NBUF;
+    uint4 kraw[NBUF][PPL], vraw[NBUF][PPL];
+    uint32_t ksc[NBUF][PPL], vsc[NBUF][PPL];
+    // Addressing: a sub-tile is 16 consecutive keys starting at a multiple of 16, wave-uniform; with contiguous slots, or pages
+    // whose size is a multiple of 16, its rows are consecutive slots, so the row base is ONE scalar computation per sub-tile and a
+    // lane adds its constant (key-in-sub-tile x row pitch + piece) -- instead of a 64-bit multiply chain per load
+    const int64_t rowb = kv.sN * ELT, srow = kv.ssN;                 // row pitch of the cache (bytes) and of the scales (halfs)
+    const int rowb32 = (int)rowb, srow32 = (int)srow;                // a sub-tile spans 16 rows: the lane part fits 32 bits
+    const bool uniform_rows = MODE == 0 || (kv.page_size % 16 == 0);
+    int vkey_l[PPL], vpc_l[PPL];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) { vkey_l[j] = (lane + 64 * j) / LPT; vpc_l[j] = (lane + 64 * j) % LPT; }
+    auto load_sub = [&](int p, int64_t kb) {
+        // prefetches past the range re-read the range's last sub-tile (never consumed); rows past `tend` inside the last
+        // sub-tile are clamped to its last valid row and masked in the softmax
+        const int64_t kbc = kb < tend ? kb : ((tend - 1) & ~(int64_t)15);
+        const int last = (int)(tend - 1 - kbc);                      // >= 0
+        const int kk = l15 < last ? l15 : last;
+        if (uniform_rows) {
+            int64_t slot_b;
+            if (MODE == 0) slot_b = slot0 + kbc;
+            else {
+                const int64_t pg = kbc / kv.page_size;
+                slot_b = cache_indices[b * max_pages + pg] * kv.page_size + (kbc - pg * kv.page_size);
+            }
+            const char* kp = kbase + slot_b * rowb;
+            const char* vp = vbase + slot_b * rowb;
+            const uint16_t* ksp = ksbase + slot_b * srow;
+            const uint16_t* vsp = vsbase + slot_b * srow;
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+                const int pc = kq + 4 * j;
+                kraw[p][j] = kv_stream_load(reinterpret_cast<const uint4*>(kp + (kk * rowb32 + pc * 16)));
+                if constexpr (QBIT == 8) ksc[p][j] = kv_stream_load(reinterpret_cast<const uint32_t*>(ksp + (kk * srow32 + pc * 2)));
+            }
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+                const int vk = vkey_l[j] < last ? vkey_l[j] : last;
+                vraw[p][j] = kv_stream_load(reinterpret_cast<const uint4*>(vp + (vk * rowb32 + vpc_l[j] * 16)));
+                if constexpr (QBIT == 8) vsc[p][j] = kv_stream_load(reinterpret_cast<const uint32_t*>(vsp + (vk * srow32 + vpc_l[j] * 2)));
+            }
+        } else {  // pages smaller than (or not aligned to) a sub-tile: every row through the page table
+            const int64_t kslot = kv_slot(kv, cache_indices, max_pages, b, kbc + kk);
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+                const int pc = kq + 4 * j;
+                kraw[p][j] = kv_stream_load(reinterpret_cast<const uint4*>(kbase + kslot * rowb + pc * 16));
+                if constexpr (QBIT == 8) ksc[p][j] = kv_stream_load(reinterpret_cast<const uint32_t*>(ksbase + kslot * srow + pc * 2));
+            }
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+                const int vk = vkey_l[j] < last ? vkey_l[j] : last;
+                const int64_t vslot = kv_slot(kv, cache_indices, max_pages, b, kbc + vk);
+                vraw[p][j] = kv_stream_load(reinterpret_cast<const uint4*>(vbase + vslot * rowb + vpc_l[j] * 16));
+                if constexpr (QBIT == 8) vsc[p][j] = kv_stream_load(reinterpret_cast<const uint32_t*>(vsbase + vslot * srow + vpc_l[j] * 2));
+            }
+        }
+    };
+
+    // one 16-key sub-tile held in register buffer P; the buffer is refilled with the sub-tile two ahead as soon as it is consumed
+    auto sub_step = [&](auto ptag, int64_t kb) {
+        constexpr int P = decltype(ptag)::value;
+        // ---- V: dequantise, hi / lo images -> this wave's LDS region (row-major [16 keys][16 channels] sub-tiles) -----------
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+            const int key = vkey_l[j], ch0 = vpc_l[j] * CH;
+            if constexpr (QBIT == 8) {
+                const h8 q0 = cvt_i8x8_f16(make_uint2(vraw[P][j].x, vraw[P][j].y)), q1 = cvt_i8x8_f16(make_uint2(vraw[P][j].z, vraw[P][j].w));
+                const h2 sc = __builtin_bit_cast(h2, vsc[P][j]);
+                h8 hi0, lo0, hi1, lo1;
+                two_product(q0, sc[0], hi0, lo0);
+                two_product(q1, sc[1], hi1, lo1);
+                uint16_t* dst = vw + (ch0 >> 4) * GQ_VSUB + key * 16;  // CH = 16: the piece is one whole sub-tile row
+                *reinterpret_cast<uint4*>(dst) = __builtin_bit_cast(uint4, hi0);
+                *reinterpret_cast<uint4*>(dst + 8) = __builtin_bit_cast(uint4, hi1);
+                *reinterpret_cast<uint4*>(dst + VW) = __builtin_bit_cast(uint4, lo0);
+                *reinterpret_cast<uint4*>(dst + VW + 8) = __builtin_bit_cast(uint4, lo1);
+            } else {
+                *reinterpret_cast<uint4*>(vw + (ch0 >> 4) * GQ_VSUB + key * 16 + (ch0 & 15)) = vraw[P][j];
+            }
+        }
+        // ---- S^T = K . Q^T, K fragments straight from the raw registers ---------------------------------------------------------
+        f4 sacc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+            if constexpr (QBIT == 8) {
+                const h8 q0 = cvt_i8x8_f16(make_uint2(kraw[P][j].x, kraw[P][j].y)), q1 = cvt_i8x8_f16(make_uint2(kraw[P][j].z, kraw[P][j].w));
+                const h2 sc = __builtin_bit_cast(h2, ksc[P][j]);
+                h8 hi0, lo0, hi1, lo1;
+                two_product(q0, sc[0], hi0, lo0);
+                two_product(q1, sc[1], hi1, lo1);
+                sacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo0, qf[2 * j], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo1, qf[2 * j + 1], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi0, qf[2 * j], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi1, qf[2 * j + 1], sacc, 0, 0, 0);
+            } else {
+                sacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, kraw[P][j]), qf[j], sacc, 0, 0, 0);
+            }
+        }
+        load_sub(P, kb + NBUF * 16 * GQ_WAVES);  // the raw registers of buffer P are free: prefetch the sub-tile NBUF ahead
+        // ---- online softmax; this lane: head l15, keys kb + kq*4 + r -----------------------------------------------------------
+        float mx = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t kpos = kb + kq * 4 + r;
+            const float sv = (kpos < tend) ? sacc[r] * sm_scale : -1e30f;
+            sacc[r] = sv;
+            mx = fmaxf(mx, sv);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(m, mx);
+        const float alpha = __expf(m - mnew);
+        m = mnew;
+        float rs = 0.f;
+        h8 pa;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t kpos = kb + kq * 4 + r;
+            const float e = (kpos < tend) ? __expf(sacc[r] - mnew) : 0.f;
+            rs += e;
+            const _Float16 hi = to_h(e);
+            pa[r] = hi;
+            pa[4 + r] = to_h(e - (float)hi);  // k-slots 4..7: the part of p that fp16 dropped
+        }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l = l * alpha + rs;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+            float ar[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, kq * 4 + r, 64);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[dt][r] *= ar[r];
+        }
+        // ---- O += P . V: V^T fragments through the transposing LDS read (same wave wrote them: program order, no barrier) ------
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const uint2 vh = gq_v_frag(vw + dt * GQ_VSUB, kq, l15);  // keys kq*4 .. +4 of channel dt*16 + l15
+            if constexpr (QBIT == 8) {
+                const uint2 vl = gq_v_frag(vw + VW + dt * GQ_VSUB, kq, l15);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, __builtin_bit_cast(h8, make_uint4(vl.x, vl.y, vl.x, vl.y)), o[dt], 0, 0, 0);
+            }
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, __builtin_bit_cast(h8, make_uint4(vh.x, vh.y, vh.x, vh.y)), o[dt], 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the reads above precede the next sub-tile's writes
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    const int64_t kb0 = tbeg + wave * 16;
+    constexpr int64_t STRIDE = 16 * GQ_WAVES;
+    // the prefetches are unconditional (keys past the range are clamped and re-read the last row), so the number of loads in
+    // flight is static at every wait
+    if (kb0 < tend) {
+#pragma unroll
+        for (int p = 0; p < NBUF; ++p) load_sub(p, kb0 + p * STRIDE);
+        for (int64_t kb = kb0; kb < tend; kb += NBUF * STRIDE) {
+            sub_step(std::integral_constant<int, 0>{}, kb);
+            if (kb + STRIDE >= tend) break;
+            sub_step(std::integral_constant<int, 1>{}, kb + STRIDE);
+            if constexpr (NBUF > 2) {
+                if (kb + 2 * STRIDE >= tend) break;
+                sub_step(std::integral_constant<int, 2>{}, kb + 2 * STRIDE);
+            }
+            if constexpr (NBUF > 3) {
+                if (kb + 3 * STRIDE >= tend) break;
+                sub_step(std::integral_constant<int, 3>{}, kb + 3 * STRIDE);
+            }
+        }
+    }
+    __syncthreads();  // every wave is done with its V region: the merge buffer may overlay them
+    // ---- merge the 8 waves: partial (o[head][d], m[head], l[head]) per wave through LDS ------------------------
+    float* mg = reinterpret_cast<float*>(smem);  // [wave][16 heads][D + 2]
+    {
+        float mr[4], lr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            mr[r] = __shfl(m, kq * 4 + r, 64);
+            lr[r] = __shfl(l, kq * 4 + r, 64);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float* row = mg + ((wave * 16) + kq * 4 + r) * (D + 2);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) row[dt * 16 + l15] = o[dt][r];
+            if (l15 == 0) { row[D] = mr[r]; row[D + 1] = lr[r]; }
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < grp * D; idx += GQ_THREADS) {
+        const int head = idx / D, d = idx - head * D;
+        float mm = -1e30f;
+        for (int w = 0; w < GQ_WAVES; ++w) mm = fmaxf(mm, mg[(w * 16 + head) * (D + 2) + D]);
+        float ll = 0.f, ov = 0.f;
+        for (int w = 0; w < GQ_WAVES; ++w) {
+            const float* row = mg + (w * 16 + head) * (D + 2);
+            const float a = __expf(row[D] - mm);
+            ll = fmaf(row[D + 1], a, ll);
+            ov = fmaf(row[d], a, ov);
+        }
+        const int hq = hk * grp + head;
+        if (split == 1) {
+            out[(b * H + hq) * (int64_t)D + d] = f2h(ov / ll);
+        } else {
+            float* ws = workspace + ((b * H + hq) * (int64_t)split + sp_i) * (D + 2);
+            ws[d] = ov;
+            if (d == 0) { ws[D] = mm; ws[D + 1] = ll; }
+        }
+    }
+}
+
+}  // namespace
+
+bool attn_decode_gqa_supported(int quant_bit, int H, int Hkv, int D) {
+    if (Hkv <= 0 || H % Hkv) return false;
+    const int grp = H / Hkv;
+    if (grp < 4 || grp > 16) return false;
+    if (quant_bit == 8) return D == 128 || D == 64;  // a row must hold >= four 16-byte pieces
+    return quant_bit == 0 && (D == 128 || D == 64 || D == 32);
+}
+
+hipError_t launch_attn_decode_gqa(hipStream_t s, const uint16_t* qkv, const KvAddr& kv, int quant_bit,
+                                  const int64_t* seq_starts, const int64_t* start_pos, const int64_t* cache_indices,
+                                  int64_t max_pages, int64_t nb, int H, int Hkv, int D, int split, float* workspace,
+                                  uint16_t* out, hipEvent_t t0, hipEvent_t t1) {
+    if (nb == 0) return hipSuccess;
+    if (!attn_decode_gqa_supported(quant_bit, H, Hkv, D)) return hipErrorInvalidValue;
+    dim3 grid((unsigned)Hkv, (unsigned)nb, (unsigned)split);
+#define GQ_LAUNCH(QB, DD, MD)                                                                                                     \
+    do {                                                                                                                          \
+        if (t0 && t1)                                                                                                             \
+            hipExtLaunchKernelGGL((attn_decode_gqa_kernel<QB, DD, MD>), grid, dim3(GQ_THREADS), 0, s, t0, t1, 0, qkv, kv, seq_starts, \
+                                  start_pos, cache_indices, max_pages, H, Hkv, split, workspace, out);                            \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((attn_decode_gqa_kernel<QB, DD, MD>), grid, dim3(GQ_THREADS), 0, s, qkv, kv, seq_starts, start_pos, \
+                               cache_indices, max_pages, H, Hkv, split, workspace, out);                                          \
+    } while (0)
+#define GQ_CASE(QB, DD)                                                              \
+    if (quant_bit == QB && D == DD) {                                                \
+        if (kv.mode == 0) GQ_LAUNCH(QB, DD, 0); else GQ_LAUNCH(QB, DD, 1);           \
+        return hipGetLastError();                                                    \
+    }
+    GQ_CASE(8, 128) GQ_CASE(0, 128) GQ_CASE(8, 64) GQ_CASE(0, 64) GQ_CASE(0, 32)
+#undef GQ_CASE
+#undef GQ_LAUNCH
+    return hipErrorInvalidValue;
+}
+
+}  // namespace pplhip

@@ -357,270 +357,4 @@ hipError_t launch_attn_prefill(hipStream_t s, const uint16_t* qkv, const KvAddr&
     return hipErrorInvalidValue;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// K8, grouped-query variant (H / Hkv >= 4, e.g. LLaMA-2-70B: 8 query heads per KV head): the VALU decode kernel would
-// read every KV row once per query head (8x the bytes, and it is VALU-bound at that point), so decode rows of GQA
-// models use the MFMA machinery of the prefill kernel with the roles changed: the "query rows" of a block are the
-// group's heads (padded to 16), one block = one (request, KV head[, K split]); the 8 waves share every staged
-// 128-key tile and each takes its own 16-key sub-tile (S^T = K.Q^T: 4 MFMAs, P.V: D/16 half-filled MFMAs), keeping a
-// private online-softmax state that is merged through LDS at the end.  Every KV byte is read from HBM once.
-// ---------------------------------------------------------------------------------------------------------------
-template <int QBIT, int D, int MODE>
-__global__ __launch_bounds__(PF_THREADS) void attn_decode_gqa_kernel(const uint16_t* __restrict__ qkv, KvAddr kv,
-                                                                     const int64_t* __restrict__ seq_starts,
-                                                                     const int64_t* __restrict__ start_pos,
-                                                                     const int64_t* __restrict__ cache_indices,
-                                                                     int64_t max_pages, int H, int Hkv, int split,
-                                                                     float* __restrict__ workspace, uint16_t* __restrict__ out) {
-    constexpr int ELT = QBIT == 8 ? 1 : 2;
-    constexpr int CH = 16 / ELT;
-    constexpr int LPT = D / CH;
-    constexpr int KSTEPS = D / 32;
-    constexpr int DT = D / 16;
-    constexpr int NITEMS = (PF_BN / 2) * LPT;
-    constexpr int IPT = (NITEMS + PF_THREADS - 1) / PF_THREADS;
-    // one LDS object: K tile | V^T tile during the loop, the per-wave partial results afterwards
-    constexpr int KS_BYTES = PF_BN * D * 2, VT_BYTES = (PF_BN / 16) * (D / 16) * PF_VSUB * 2, MERGE_BYTES = 8 * 16 * (D + 2) * 4;
-    constexpr int LDS_BYTES = (KS_BYTES + VT_BYTES) > MERGE_BYTES ? (KS_BYTES + VT_BYTES) : MERGE_BYTES;
-    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
-    uint16_t* const Ks = reinterpret_cast<uint16_t*>(smem);
-    uint16_t* const Vs = reinterpret_cast<uint16_t*>(smem + KS_BYTES);
-
-    const int hk = blockIdx.x;
-    const int64_t b = blockIdx.y;
-    const int sp_i = blockIdx.z;
-    const int grp = H / Hkv;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l15 = lane & 15, kq = lane >> 4;
-    const int64_t rowstride = (int64_t)(H + 2 * Hkv) * D;
-    const int64_t qpos = start_pos[b];
-    const int64_t kv_len = qpos + 1;
-    const int64_t per = ((kv_len + split - 1) / split + PF_BN - 1) / PF_BN * PF_BN;  // whole tiles per split
-    const int64_t tbeg = sp_i * per;
-    const int64_t tend = (tbeg + per < kv_len) ? tbeg + per : kv_len;
-
-    // Q fragments (B operand): lane (n = head l15 of the group, kq) holds q[head][ks*32 + kq*8 .. +8]; heads >= grp: 0
-    h8 qf[KSTEPS];
-    {
-        const uint16_t* qrow = qkv + seq_starts[b] * rowstride + (int64_t)(hk * grp + (l15 < grp ? l15 : 0)) * D;
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            const uint4 v = *reinterpret_cast<const uint4*>(qrow + ks * 32 + kq * 8);
-            qf[ks] = __builtin_bit_cast(h8, l15 < grp ? v : make_uint4(0, 0, 0, 0));
-        }
-    }
-    f4 o[DT];
-#pragma unroll
-    for (int i = 0; i < DT; ++i) o[i] = f4{0.f, 0.f, 0.f, 0.f};
-    float m = -1e30f, l = 0.f;
-    const float sm_scale = 1.0f / sqrtf((float)D);
-
-    const int64_t slot0 = MODE == 0 ? cache_indices[b] : 0;  // contiguous mode: first slot of the request
-    const char* kbase = reinterpret_cast<const char*>(kv.cache) + (int64_t)hk * kv.sH * ELT;
-    const char* vbase = kbase + kv.sKV * ELT;
-    const uint16_t* ksbase = kv.scale + (int64_t)hk * kv.ssH;
-    const uint16_t* vsbase = ksbase + kv.ssKV;
-
-    // TWO tiles in flight (register double buffer): a block streams one KV head of one request, so the bytes it keeps
-    // outstanding set its share of the HBM bandwidth
-    uint4 kraw[2][IPT][2], vraw[2][IPT][2];
-    uint32_t ksc[2][IPT][2], vsc[2][IPT][2];
-    auto load_tile = [&](int p, int64_t key0) {
-#pragma unroll
-        for (int it = 0; it < IPT; ++it) {
-            const int item = threadIdx.x + it * PF_THREADS;
-            if (NITEMS % PF_THREADS == 0 || item < NITEMS) {  // compile-time true for D = 128: no exec branch around the loads
-                const int c = item % LPT, kp = item / LPT;
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    int64_t key = key0 + 2 * kp + e;
-                    if (key >= tend) key = tend - 1;
-                    const int64_t slot = MODE == 0 ? slot0 + key : kv_slot(kv, cache_indices, max_pages, b, key);
-                    kraw[p][it][e] = kv_stream_load(reinterpret_cast<const uint4*>(kbase + (slot * kv.sN + c * CH) * ELT));
-                    vraw[p][it][e] = kv_stream_load(reinterpret_cast<const uint4*>(vbase + (slot * kv.sN + c * CH) * ELT));
-                    if constexpr (QBIT == 8) {
-                        ksc[p][it][e] = kv_stream_load(reinterpret_cast<const uint32_t*>(ksbase + slot * kv.ssN + c * 2));
-                        vsc[p][it][e] = kv_stream_load(reinterpret_cast<const uint32_t*>(vsbase + slot * kv.ssN + c * 2));
-                    }
-                }
-            }
-        }
-    };
-    auto store_tile = [&](int p) {
-#pragma unroll
-        for (int it = 0; it < IPT; ++it) {
-            const int item = threadIdx.x + it * PF_THREADS;
-            if (NITEMS % PF_THREADS == 0 || item < NITEMS) {  // compile-time true for D = 128: no exec branch around the loads
-                const int c = item % LPT, kp = item / LPT;
-                const int ch0 = c * CH;
-                // the piece as CH/8 groups of 8 fp16, per key of the pair: int8 -> fp16 exactly (v_perm under the exponent),
-                // times the group's fp16 scale in packed fp16 (one rounding of q * scale, as the oracle's dequantisation)
-                h8 kh[2][CH / 8], vh[2][CH / 8];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    if constexpr (QBIT == 8) {
-                        const h8 k0 = cvt_i8x8_f16(make_uint2(kraw[p][it][e].x, kraw[p][it][e].y)), k1 = cvt_i8x8_f16(make_uint2(kraw[p][it][e].z, kraw[p][it][e].w));
-                        const h8 v0 = cvt_i8x8_f16(make_uint2(vraw[p][it][e].x, vraw[p][it][e].y)), v1 = cvt_i8x8_f16(make_uint2(vraw[p][it][e].z, vraw[p][it][e].w));
-                        const h2 ksc2 = __builtin_bit_cast(h2, ksc[p][it][e]), vsc2 = __builtin_bit_cast(h2, vsc[p][it][e]);
-                        kh[e][0] = k0 * ksc2[0]; kh[e][1] = k1 * ksc2[1];
-                        vh[e][0] = v0 * vsc2[0]; vh[e][1] = v1 * vsc2[1];
-                    } else {
-                        kh[e][0] = __builtin_bit_cast(h8, kraw[p][it][e]);
-                        vh[e][0] = __builtin_bit_cast(h8, vraw[p][it][e]);
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int key = 2 * kp + e;
-#pragma unroll
-                    for (int cc = 0; cc < CH / 8; ++cc) {
-                        const int chunk = (ch0 / 8 + cc) ^ k_swz<D>(key);
-                        *reinterpret_cast<uint4*>(&Ks[key * D + chunk * 8]) = __builtin_bit_cast(uint4, kh[e][cc]);
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int key = 2 * kp + e;
-#pragma unroll
-                    for (int cc = 0; cc < CH / 8; ++cc) {
-                        const int ch = ch0 + cc * 8;
-                        *reinterpret_cast<uint4*>(&Vs[((key >> 4) * (D / 16) + (ch >> 4)) * PF_VSUB + (key & 15) * 16 + (ch & 15)]) =
-                            __builtin_bit_cast(uint4, vh[e][cc]);
-                    }
-                }
-            }
-        }
-    };
-
-    // the prefetches are unconditional (keys past the range are clamped inside load_tile and re-read the last row):
-    // with a static number of loads per iteration hipcc can wait for exactly the older tile (vmcnt(8..15)); a guarded
-    // prefetch makes it drain both
-    if (tbeg < tend) {
-        load_tile(0, tbeg);
-        load_tile(1, tbeg + PF_BN);
-    }
-    // one tile: buffer P -> LDS, refill buffer P with tile t+2, multiply.  The loop below alternates P = 0, 1 in straight-
-    // line code, so the age of each register buffer is static at every wait.
-    auto tile_step = [&](auto ptag, int64_t key0) {
-        constexpr int P = decltype(ptag)::value;
-        store_tile(P);
-        __syncthreads();
-        load_tile(P, key0 + 2 * PF_BN);
-        const int64_t kbase_w = key0 + wave * 16;  // this wave's 16-key sub-tile
-        if (kbase_w < tend) {
-            f4 sacc = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) {
-                const int key = wave * 16 + l15;
-                const int chunk = (ks * 4 + kq) ^ k_swz<D>(key);
-                const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&Ks[key * D + chunk * 8]));
-                sacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[ks], sacc, 0, 0, 0);
-            }
-            // lane: head l15, keys kbase_w + kq*4 + r
-            float mx = -1e30f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t kpos = kbase_w + kq * 4 + r;
-                const float sv = (kpos < tend) ? sacc[r] * sm_scale : -1e30f;
-                sacc[r] = sv;
-                mx = fmaxf(mx, sv);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mnew = fmaxf(m, mx);
-            const float alpha = __expf(m - mnew);
-            m = mnew;
-            float rs = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t kpos = kbase_w + kq * 4 + r;
-                const float e = (kpos < tend) ? __expf(sacc[r] - mnew) : 0.f;
-                sacc[r] = e;
-                rs += e;
-            }
-            rs += __shfl_xor(rs, 16, 64);
-            rs += __shfl_xor(rs, 32, 64);
-            l = l * alpha + rs;
-            float ar[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, kq * 4 + r, 64);
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[dt][r] *= ar[r];
-            // P.V over this wave's 16 keys: k-slots 0..3 = keys kq*4 + r, k-slots 4..7 unused (zero)
-            h8 pa = {to_h(sacc[0]), to_h(sacc[1]), to_h(sacc[2]), to_h(sacc[3]), (_Float16)0.f, (_Float16)0.f,
-                     (_Float16)0.f, (_Float16)0.f};
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const uint2 lo = v_frag_tr(Vs, wave * DT + dt, kq, l15);  // keys wave*16 + kq*4 .. +4 of channel dt*16 + l15
-                const h8 bv = __builtin_bit_cast(h8, make_uint4(lo.x, lo.y, 0u, 0u));
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, bv, o[dt], 0, 0, 0);
-            }
-        }
-        __syncthreads();
-    };
-    for (int64_t key0 = tbeg; key0 < tend; key0 += 2 * PF_BN) {
-        tile_step(std::integral_constant<int, 0>{}, key0);
-        if (key0 + PF_BN >= tend) break;
-        tile_step(std::integral_constant<int, 1>{}, key0 + PF_BN);
-    }
-    // ---- merge the 8 waves: partial (o[head][d], m[head], l[head]) per wave through LDS ------------------------
-    float* mg = reinterpret_cast<float*>(smem);  // [wave][16 heads][D + 2]
-    {
-        float mr[4], lr[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            mr[r] = __shfl(m, kq * 4 + r, 64);
-            lr[r] = __shfl(l, kq * 4 + r, 64);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float* row = mg + ((wave * 16) + kq * 4 + r) * (D + 2);
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) row[dt * 16 + l15] = o[dt][r];
-            if (l15 == 0) { row[D] = mr[r]; row[D + 1] = lr[r]; }
-        }
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < grp * D; idx += PF_THREADS) {
-        const int head = idx / D, d = idx - head * D;
-        float mm = -1e30f;
-        for (int w = 0; w < 8; ++w) mm = fmaxf(mm, mg[(w * 16 + head) * (D + 2) + D]);
-        float ll = 0.f, ov = 0.f;
-        for (int w = 0; w < 8; ++w) {
-            const float* row = mg + (w * 16 + head) * (D + 2);
-            const float a = __expf(row[D] - mm);
-            ll = fmaf(row[D + 1], a, ll);
-            ov = fmaf(row[d], a, ov);
-        }
-        const int hq = hk * grp + head;
-        if (split == 1) {
-            out[(b * H + hq) * (int64_t)D + d] = f2h(ov / ll);
-        } else {
-            float* ws = workspace + ((b * H + hq) * (int64_t)split + sp_i) * (D + 2);
-            ws[d] = ov;
-            if (d == 0) { ws[D] = mm; ws[D + 1] = ll; }
-        }
-    }
-}
-
-hipError_t launch_attn_decode_gqa(hipStream_t s, const uint16_t* qkv, const KvAddr& kv, int quant_bit,
-                                  const int64_t* seq_starts, const int64_t* start_pos, const int64_t* cache_indices,
-                                  int64_t max_pages, int64_t nb, int H, int Hkv, int D, int split, float* workspace,
-                                  uint16_t* out) {
-    if (nb == 0) return hipSuccess;
-    if (H / Hkv > 16 || H % Hkv) return hipErrorInvalidValue;
-    dim3 grid((unsigned)Hkv, (unsigned)nb, (unsigned)split);
-#define GQ_CASE(QB, DD)                                                                                           \
-    if (quant_bit == QB && D == DD) {                                                                             \
-        if (kv.mode == 0) hipLaunchKernelGGL((attn_decode_gqa_kernel<QB, DD, 0>), grid, dim3(PF_THREADS), 0, s, qkv, kv, seq_starts, start_pos, cache_indices, max_pages, H, Hkv, split, workspace, out); \
-        else hipLaunchKernelGGL((attn_decode_gqa_kernel<QB, DD, 1>), grid, dim3(PF_THREADS), 0, s, qkv, kv, seq_starts, start_pos, cache_indices, max_pages, H, Hkv, split, workspace, out); \
-        return hipGetLastError();                                                                                 \
-    }
-    GQ_CASE(8, 128) GQ_CASE(0, 128) GQ_CASE(8, 64) GQ_CASE(0, 64) GQ_CASE(8, 32) GQ_CASE(0, 32)
-#undef GQ_CASE
-    return hipErrorInvalidValue;
-}
-
 }  // namespace pplhip

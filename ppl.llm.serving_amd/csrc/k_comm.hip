@@ -39,7 +39,24 @@ typedef unsigned long long u64;
 __device__ __forceinline__ uint32_t ld_sys(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void st_sys(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ u64 ld_sys(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void st_sys(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// 16-byte system-scope accesses (global_load/store_dwordx4 ... sc0 sc1): the same cache-bypass bits the 8-byte atomics above
+// compile to, at the widest access the memory pipeline has -- half the instructions per byte pulled over a link.  Issued from
+// inline asm (HIP has no 16-byte atomic): the compiler does not count them, so every batch of loads is followed by wait16(),
+// which ties the loaded registers to an s_waitcnt vmcnt(0).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 ld_sys16(const void* p) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void st_sys16(void* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+template <int N>
+__device__ __forceinline__ void wait16(u32x4 (&v)[N]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));  // uses of v[i] stay below the wait
+}
 
 // block b of this rank <-> block b of every peer.  END: the block's data stores must have landed before the flag goes out.
 template <bool END>
@@ -71,10 +88,10 @@ __device__ __forceinline__ void cross_rank_barrier(const P2pPeers& peers, int me
     __syncthreads();
 }
 
-__device__ __forceinline__ void add4(float* acc, u64 v) {
-    const h4 h = __builtin_bit_cast(h4, v);
+__device__ __forceinline__ void add8(float* acc, u32x4 v) {
+    const h8 h = __builtin_bit_cast(h8, v);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] += (float)h[i];
+    for (int i = 0; i < 8; ++i) acc[i] += (float)h[i];
 }
 
 // N > 0: compile-time rank count (2, 4, 8); N == 0: any n <= P2P_MAX_RANKS
@@ -86,30 +103,32 @@ __global__ __launch_bounds__(512) void p2p_allreduce_kernel(P2pPeers peers, int 
     const int64_t per = (granules + n - 1) / n;  // slice of rank r: granules [r * per, min((r + 1) * per, granules))
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
     cross_rank_barrier<false>(peers, me, n, P2P_FLAGS_START, epoch, timeout_ticks, status);
-    {   // reduce-scatter into my scratch slice
+    {   // reduce-scatter into my scratch slice (granule = 16 bytes = 8 fp16)
         const int64_t lo = per * me, hi = (lo + per < granules) ? lo + per : granules;
-        u64* mine = reinterpret_cast<u64*>(peers.base[me] + scratch_off);
+        char* mine = peers.base[me] + scratch_off;
         for (int64_t g = lo + tid; g < hi; g += nthr) {
-            u64 v[MAXN];
+            u32x4 v[MAXN];
 #pragma unroll
             for (int r = 0; r < MAXN; ++r)
-                if (r < n) v[r] = ld_sys(reinterpret_cast<const u64*>(peers.base[r] + data_off) + g);
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                v[r] = r < n ? ld_sys16(peers.base[r] + data_off + g * 16) : u32x4{0, 0, 0, 0};
+            wait16(v);
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < MAXN; ++r)
-                if (r < n) add4(acc, v[r]);  // rank order 0 .. n-1 on every element: one result for the whole group
-            const h4 o = {to_h(acc[0]), to_h(acc[1]), to_h(acc[2]), to_h(acc[3])};
-            st_sys(mine + (g - lo), __builtin_bit_cast(u64, o));
+                if (r < n) add8(acc, v[r]);  // rank order 0 .. n-1 on every element: one result for the whole group
+            const h8 o = {to_h(acc[0]), to_h(acc[1]), to_h(acc[2]), to_h(acc[3]), to_h(acc[4]), to_h(acc[5]), to_h(acc[6]), to_h(acc[7])};
+            st_sys16(mine + (g - lo) * 16, __builtin_bit_cast(u32x4, o));
         }
     }
     cross_rank_barrier<true>(peers, me, n, P2P_FLAGS_MID, epoch, timeout_ticks, status);
     {   // all-gather: slice r from rank r's scratch -> my buffer (ordinary stores)
-        u64* out = reinterpret_cast<u64*>(peers.base[me] + data_off);
+        u32x4* out = reinterpret_cast<u32x4*>(peers.base[me] + data_off);
         for (int64_t g = tid; g < per; g += nthr) {
-            u64 v[MAXN];
+            u32x4 v[MAXN];
 #pragma unroll
             for (int r = 0; r < MAXN; ++r)
-                if (r < n && per * r + g < granules) v[r] = ld_sys(reinterpret_cast<const u64*>(peers.base[r] + scratch_off) + g);
+                v[r] = (r < n && per * r + g < granules) ? ld_sys16(peers.base[r] + scratch_off + g * 16) : u32x4{0, 0, 0, 0};
+            wait16(v);
 #pragma unroll
             for (int r = 0; r < MAXN; ++r)
                 if (r < n && per * r + g < granules) out[per * r + g] = v[r];
@@ -117,17 +136,29 @@ __global__ __launch_bounds__(512) void p2p_allreduce_kernel(P2pPeers peers, int 
     }
 }
 
-// logits shards: rows x row_granules 8-byte granules at src_off of every rank's region (rank r's [rows, V/n] block)
+// logits shards: rows x row_granules granules (G = 8 or 16 bytes) at src_off of every rank's region (rank r's [rows, V/n] block)
 // -> columns [r * row_granules, (r + 1) * row_granules) of my [rows, dst_row_granules] matrix (ordinary local memory)
-__global__ __launch_bounds__(512) void p2p_allgather_kernel(P2pPeers peers, int me, int n, size_t src_off, u64* __restrict__ dst,
+template <int GB>
+__global__ __launch_bounds__(512) void p2p_allgather_kernel(P2pPeers peers, int me, int n, size_t src_off, char* __restrict__ dst,
                                                             int64_t rows, int64_t row_granules, int64_t dst_row_granules,
                                                             uint32_t epoch, u64 timeout_ticks, uint32_t* status) {
     cross_rank_barrier<false>(peers, me, n, P2P_FLAGS_START, epoch, timeout_ticks, status);
     const int64_t total = rows * row_granules;
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = g / row_granules, col = g - row * row_granules;
-        for (int r = 0; r < n; ++r)
-            dst[row * dst_row_granules + (int64_t)r * row_granules + col] = ld_sys(reinterpret_cast<const u64*>(peers.base[r] + src_off) + g);
+        if (GB == 16) {
+            u32x4 v[P2P_MAX_RANKS];
+#pragma unroll
+            for (int r = 0; r < P2P_MAX_RANKS; ++r) v[r] = r < n ? ld_sys16(peers.base[r] + src_off + g * 16) : u32x4{0, 0, 0, 0};
+            wait16(v);
+#pragma unroll
+            for (int r = 0; r < P2P_MAX_RANKS; ++r)
+                if (r < n) reinterpret_cast<u32x4*>(dst)[row * dst_row_granules + (int64_t)r * row_granules + col] = v[r];
+        } else {
+            for (int r = 0; r < n; ++r)
+                reinterpret_cast<u64*>(dst)[row * dst_row_granules + (int64_t)r * row_granules + col] =
+                    ld_sys(reinterpret_cast<const u64*>(peers.base[r] + src_off) + g);
+        }
     }
 }
 
@@ -141,7 +172,7 @@ __global__ __launch_bounds__(256) void p2p_pattern_kernel(uint16_t* __restrict__
 }
 
 int grid_for(int64_t granules_per_rank) {
-    // 512 threads x up to 8 granules each per block; enough blocks to keep every link busy, few enough that the spinning
+    // 512 threads x up to 8 granules (16 B) each per block; enough blocks to keep every link busy, few enough that the spinning
     // blocks of several ranks emulated on ONE device (tests) never fill it
     int64_t b = (granules_per_rank + 512 * 8 - 1) / (512 * 8);
     if (b < 1) b = 1;
@@ -161,9 +192,9 @@ hipError_t launch_p2p_pattern(hipStream_t s, uint16_t* halfs, int64_t cnt, float
 
 hipError_t launch_p2p_allreduce(hipStream_t s, const P2pPeers& peers, int me, int n, size_t data_off, size_t scratch_off, int64_t count,
                                 uint32_t epoch, uint64_t timeout_ticks, uint32_t* status) {
-    if (n < 2 || n > P2P_MAX_RANKS || count % 4 || data_off % 8 || scratch_off % 8) return hipErrorInvalidValue;
+    if (n < 2 || n > P2P_MAX_RANKS || count % 8 || data_off % 16 || scratch_off % 16) return hipErrorInvalidValue;
     if (count == 0) return hipSuccess;
-    const int64_t granules = count / 4;
+    const int64_t granules = count / 8;
     const dim3 grid(grid_for((granules + n - 1) / n)), block(512);
 #define AR(NN) hipLaunchKernelGGL(p2p_allreduce_kernel<NN>, grid, block, 0, s, peers, me, n, data_off, scratch_off, granules, epoch, (u64)timeout_ticks, status)
     if (n == 2) AR(2); else if (n == 4) AR(4); else if (n == 8) AR(8); else AR(0);
@@ -175,9 +206,15 @@ hipError_t launch_p2p_allgather(hipStream_t s, const P2pPeers& peers, int me, in
                                 int64_t row_bytes, int64_t dst_row_bytes, uint32_t epoch, uint64_t timeout_ticks, uint32_t* status) {
     if (n < 2 || n > P2P_MAX_RANKS || row_bytes % 8 || dst_row_bytes % 8 || src_off % 8) return hipErrorInvalidValue;
     if (rows == 0 || row_bytes == 0) return hipSuccess;
-    const dim3 grid(grid_for(rows * row_bytes / 8)), block(512);
-    hipLaunchKernelGGL(p2p_allgather_kernel, grid, block, 0, s, peers, me, n, src_off, reinterpret_cast<u64*>(dst), rows, row_bytes / 8,
-                       dst_row_bytes / 8, epoch, (u64)timeout_ticks, status);
+    const bool wide = row_bytes % 16 == 0 && dst_row_bytes % 16 == 0 && src_off % 16 == 0 && (uintptr_t)dst % 16 == 0;
+    const int gb = wide ? 16 : 8;
+    const dim3 grid(grid_for(rows * row_bytes / gb)), block(512);
+    if (wide)
+        hipLaunchKernelGGL(p2p_allgather_kernel<16>, grid, block, 0, s, peers, me, n, src_off, reinterpret_cast<char*>(dst), rows, row_bytes / 16,
+                           dst_row_bytes / 16, epoch, (u64)timeout_ticks, status);
+    else
+        hipLaunchKernelGGL(p2p_allgather_kernel<8>, grid, block, 0, s, peers, me, n, src_off, reinterpret_cast<char*>(dst), rows, row_bytes / 8,
+                           dst_row_bytes / 8, epoch, (u64)timeout_ticks, status);
     return hipGetLastError();
 }
 

@@ -62,24 +62,82 @@ hipError_t launch_sample_greedy(hipStream_t s, const float* logits, const float*
     return hipGetLastError();
 }
 
-// top-k / top-p: candidates = k largest x (ties: lower index first) found by k block-wide selection passes
-// (the row stays L2-resident); p = softmax over candidates; keep the shortest prefix with cumulative p >= top_p
-// (at least one); pick the first candidate whose cumulative mass exceeds rand * kept mass.
-// top_k <= 0 (the usual "pure top-p" request): the candidates are the whole vocabulary -- p is the softmax over ALL
-// logits -- and the selection passes stop as soon as the nucleus is complete (or at TOPK_MAX candidates).
-// top_k > TOPK_MAX is clamped to TOPK_MAX.  A per-request parameter never fails the batch.
+// top-k / top-p.  Specification (DESIGN.md "sampler", restated by ref_sample): candidates = the k largest x = logits / temperature
+// (ties: lower index first), k = top_k clamped to [1, TOPK_MAX]; p = softmax over the candidates; keep the shortest prefix of the
+// sorted candidates whose cumulative p reaches top_p (at least one); pick the first kept candidate whose cumulative mass exceeds
+// rand * kept mass.  top_k <= 0 (the usual "pure top-p" request): the candidates are the TOPK_MAX most probable tokens and p is
+// the softmax over the WHOLE vocabulary (the nucleus is cut at TOPK_MAX candidates; the oracle does the same).  A per-request
+// parameter never fails the batch.
+// Work per row (one 256-thread block): max + total mass (2 passes over the row, which stays L2-resident), a 4 x 8-bit radix
+// selection of the k-th largest value on order-preserving keys (4 passes; + 3 passes over the indices only when equal values
+// straddle the cut), one gather pass, a bitonic sort of <= 1024 candidates in LDS and block-wide scans for the two cumulative
+// decisions: ~7 row passes whatever k is.  (Round 2 ran one whole-row arg-max pass PER candidate: 50 passes at top_k = 50, up
+// to 1024 in pure top-p mode -- ADVICE r2.)
 constexpr int TOPK_MAX = 1024;
+
+__device__ __forceinline__ uint32_t order_key(float x) {  // larger float <=> larger key
+    const uint32_t u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// block-wide inclusive scan of one int per thread (256 threads = 4 waves); `wsum` = 4 ints of LDS
+__device__ __forceinline__ int block_scan_incl(int v, int* wsum) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[w] = v;
+    __syncthreads();
+    for (int i = 0; i < w; ++i) v += wsum[i];
+    return v;
+}
+
+// One radix-selection pass over `vocab` elements.  key(i) -> uint32, live(i) -> bool (element still matches the digits fixed so
+// far).  Counts the digit `(key >> shift) & 255` of the live elements (run-length aggregated per thread: logits of one row share
+// their top byte, a plain atomic per element would serialise on one LDS word), then finds the digit that holds the `need`-th
+// element counting from the top (DESC) or from the bottom (ascending).  Returns the digit; `need` becomes the rank inside it and
+// `*count` the number of live elements that share it.
+template <bool DESC, typename KeyFn>
+__device__ __forceinline__ int radix_pass(int vocab, int shift, KeyFn key_live, int& need, int* count, int* hist, int* wsum, int* sel) {
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    int run_bin = -1, run = 0;
+    for (int i = threadIdx.x; i < vocab; i += 256) {
+        uint32_t k;
+        if (!key_live(i, k)) continue;
+        const int bin = (int)((k >> shift) & 255u);
+        if (bin == run_bin) { ++run; continue; }
+        if (run) atomicAdd(&hist[run_bin], run);
+        run_bin = bin; run = 1;
+    }
+    if (run) atomicAdd(&hist[run_bin], run);
+    __syncthreads();
+    const int my_bin = DESC ? 255 - (int)threadIdx.x : (int)threadIdx.x;
+    const int c = hist[my_bin];
+    const int incl = block_scan_incl(c, wsum);
+    if (incl - c < need && need <= incl) { sel[0] = my_bin; sel[1] = need - (incl - c); sel[2] = c; }
+    __syncthreads();
+    const int bin = sel[0];
+    need = sel[1];
+    *count = sel[2];
+    __syncthreads();
+    return bin;
+}
+
 __global__ __launch_bounds__(256) void sample_topk_topp_kernel(const float* __restrict__ logits,
                                                                const float* __restrict__ temperatures,
                                                                const float* __restrict__ top_p, const float* __restrict__ rnd,
                                                                int vocab, int stride, int top_k, float default_top_p,
                                                                int32_t* __restrict__ out_tok, float* __restrict__ out_lp) {
-    __shared__ float sv[4];
-    __shared__ int si[4];
-    __shared__ float ss[4];
-    __shared__ float cv[TOPK_MAX];
+    __shared__ float sf[4];
+    __shared__ int wsum[4], sel[4], hist[256];
+    __shared__ float cv[TOPK_MAX];   // candidate values, later their masses exp(x - max)
+    __shared__ float cum[TOPK_MAX];  // inclusive cumulative mass of the sorted candidates
     __shared__ int ci[TOPK_MAX];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x;
     const float* row = logits + (int64_t)b * stride;
     const float t = (temperatures && temperatures[b] > 0.f) ? temperatures[b] : 1.0f;
     const float invt = 1.0f / t;
@@ -87,53 +145,132 @@ __global__ __launch_bounds__(256) void sample_topk_topp_kernel(const float* __re
     int k = full ? TOPK_MAX : (top_k < TOPK_MAX ? top_k : TOPK_MAX);
     if (k > vocab) k = vocab;
     const float tp = top_p ? top_p[b] : default_top_p;
-    float pv = INFINITY, mx = 0.f, se = 0.f, cum = 0.f;
-    int pi = -1, n = 0;
-    for (int it = 0; it < k; ++it) {
-        ArgMax am{-INFINITY, 0x7fffffff};
-        for (int i = threadIdx.x; i < vocab; i += 256) {
-            const float x = row[i] * invt;
-            if (x < pv || (x == pv && i > pi)) am = am_better(am, ArgMax{x, i});
+
+    // row maximum and total mass
+    float mx = -INFINITY;
+    for (int i = tid; i < vocab; i += 256) mx = fmaxf(mx, row[i] * invt);
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) sf[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sf[0], sf[1]), fmaxf(sf[2], sf[3]));
+    __syncthreads();
+    float se = 0.f;
+    for (int i = tid; i < vocab; i += 256) se += __expf(row[i] * invt - mx);
+    se = wave_sum(se);
+    if ((tid & 63) == 0) sf[tid >> 6] = se;
+    __syncthreads();
+    se = sf[0] + sf[1] + sf[2] + sf[3];
+    __syncthreads();
+
+    // the k-th largest key, most significant byte first
+    uint32_t prefix = 0, mask = 0;
+    int need = k, n_eq = 0;
+#pragma unroll 1
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        const int bin = radix_pass<true>(vocab, shift,
+            [&](int i, uint32_t& kk) { kk = order_key(row[i] * invt); return (kk & mask) == prefix; }, need, &n_eq, hist, wsum, sel);
+        prefix |= (uint32_t)bin << shift;
+        mask |= 255u << shift;
+    }
+    // `need` of the `n_eq` elements whose key equals the cut value are candidates: the ones with the lowest indices
+    int idx_cut = 0x7fffffff;
+    if (need < n_eq) {
+        uint32_t ip = 0, im = 0;
+        int dummy = 0;
+#pragma unroll 1
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            const int bin = radix_pass<false>(vocab, shift,
+                [&](int i, uint32_t& kk) { kk = (uint32_t)i; return order_key(row[i] * invt) == prefix && ((uint32_t)i & im) == ip; },
+                need, &dummy, hist, wsum, sel);
+            ip |= (uint32_t)bin << shift;
+            im |= 255u << shift;
         }
-        am = wave_argmax(am);
-        if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = am.v; si[threadIdx.x >> 6] = am.i; }
-        __syncthreads();
-        am = ArgMax{sv[0], si[0]};
-        for (int w = 1; w < 4; ++w) am = am_better(am, ArgMax{sv[w], si[w]});
-        if (threadIdx.x == 0) { cv[it] = am.v; ci[it] = am.i; }
-        pv = am.v; pi = am.i;
-        n = it + 1;
-        if (it == 0) {  // the row maximum is known: total mass of the row
-            mx = am.v;
-            float part = 0.f;
-            for (int i = threadIdx.x; i < vocab; i += 256) part += __expf(row[i] * invt - mx);
-            part = wave_sum(part);
-            if ((threadIdx.x & 63) == 0) ss[threadIdx.x >> 6] = part;
+        idx_cut = (int)ip;
+    }
+    // gather the k candidates, pad to a power of two, sort by (value descending, index ascending)
+    if (tid == 0) sel[3] = 0;
+    __syncthreads();
+    for (int i = tid; i < vocab; i += 256) {
+        const float x = row[i] * invt;
+        const uint32_t kk = order_key(x);
+        if (kk > prefix || (kk == prefix && i <= idx_cut)) {
+            const int slot = atomicAdd(&sel[3], 1);
+            if (slot < TOPK_MAX) { cv[slot] = x; ci[slot] = i; }
+        }
+    }
+    int n2 = 1;
+    while (n2 < k) n2 <<= 1;
+    __syncthreads();
+    for (int i = k + tid; i < n2; i += 256) { cv[i] = -INFINITY; ci[i] = 0x7fffffff; }
+    __syncthreads();
+    for (int size = 2; size <= n2; size <<= 1)
+        for (int str = size >> 1; str > 0; str >>= 1) {
+            for (int p = tid; p < (n2 >> 1); p += 256) {
+                const int lo = ((p / str) * str * 2) + (p % str), hi = lo + str;
+                const bool desc = ((lo & size) == 0);  // this sub-sequence ends up "best first"
+                const float va = cv[lo], vb = cv[hi];
+                const int ia = ci[lo], ib = ci[hi];
+                const bool a_first = va > vb || (va == vb && ia < ib);  // a ranks before b
+                if (a_first != desc) { cv[lo] = vb; cv[hi] = va; ci[lo] = ib; ci[hi] = ia; }
+            }
             __syncthreads();
-            se = ss[0] + ss[1] + ss[2] + ss[3];
+        }
+    // masses and their inclusive scan (Hillis-Steele over <= 1024 entries, ping-pong between cum and cv is not needed: each
+    // thread owns entries tid, tid + 256, ... and reads strictly lower ones written in the previous round)
+    const float vsel_dummy = 0.f; (void)vsel_dummy;
+    float xv[TOPK_MAX / 256];
+#pragma unroll
+    for (int j = 0; j < TOPK_MAX / 256; ++j) {
+        const int i = tid + j * 256;
+        xv[j] = i < k ? cv[i] : -INFINITY;  // keep the candidate's x for the logprob
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TOPK_MAX / 256; ++j) {
+        const int i = tid + j * 256;
+        if (i < n2) { const float e = i < k ? expf(xv[j] - mx) : 0.f; cv[i] = e; cum[i] = e; }
+    }
+    __syncthreads();
+    for (int o = 1; o < n2; o <<= 1) {
+        float add[TOPK_MAX / 256];
+#pragma unroll
+        for (int j = 0; j < TOPK_MAX / 256; ++j) {
+            const int i = tid + j * 256;
+            add[j] = (i < n2 && i >= o) ? cum[i - o] : 0.f;
         }
         __syncthreads();
-        if (full) {     // (block-uniform: every thread adds the same broadcast values)
-            cum += __expf(am.v - mx);
-            if (cum >= tp * se) break;
+#pragma unroll
+        for (int j = 0; j < TOPK_MAX / 256; ++j) {
+            const int i = tid + j * 256;
+            if (i < n2) cum[i] += add[j];
         }
+        __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        float tot = 0.f;
-        if (full) tot = se;
-        else for (int i = 0; i < n; ++i) tot += expf(cv[i] - mx);
-        float c1 = 0.f;
-        int keep = 0;
-        for (int i = 0; i < n; ++i) { c1 += expf(cv[i] - mx) / tot; keep = i + 1; if (c1 >= tp) break; }
-        float ktot = 0.f;
-        for (int i = 0; i < keep; ++i) ktot += expf(cv[i] - mx);
-        const float target = rnd[b] * ktot;
-        float c2 = 0.f;
-        int sel = keep - 1;
-        for (int i = 0; i < keep; ++i) { c2 += expf(cv[i] - mx); if (c2 > target) { sel = i; break; } }
-        out_tok[b] = ci[sel];
-        out_lp[b] = cv[sel] - (mx + logf(se));
+    // keep = 1 + first i with cum[i] / tot >= tp (all k when none); tot = whole-row mass in pure top-p mode
+    const float tot = full ? se : cum[k - 1];
+    if (tid == 0) { sel[0] = k - 1; sel[1] = 0x7fffffff; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TOPK_MAX / 256; ++j) {
+        const int i = tid + j * 256;
+        if (i < k && cum[i] / tot >= tp) atomicMin(&sel[0], i);
     }
+    __syncthreads();
+    const int keep = sel[0] + 1;
+    const float target = rnd[b] * cum[keep - 1];
+#pragma unroll
+    for (int j = 0; j < TOPK_MAX / 256; ++j) {
+        const int i = tid + j * 256;
+        if (i < keep && cum[i] > target) atomicMin(&sel[1], i);
+    }
+    __syncthreads();
+    const int pick = sel[1] < keep ? sel[1] : keep - 1;
+#pragma unroll
+    for (int j = 0; j < TOPK_MAX / 256; ++j)
+        if (tid + j * 256 == pick) {
+            out_tok[b] = ci[pick];
+            out_lp[b] = xv[j] - (mx + logf(se));
+        }
 }
 
 size_t sample_topk_workspace_bytes(int, int, int) { return 0; }

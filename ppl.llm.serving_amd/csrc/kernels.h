@@ -39,12 +39,14 @@ hipError_t launch_attn_prefill(hipStream_t s, const uint16_t* qkv, const KvAddr&
                                int64_t max_pages, int64_t b0, int64_t B, int H, int Hkv, int D, int64_t max_seq_len,
                                uint16_t* out);
 
-// grouped-query decode (H/Hkv >= 4): MFMA kernel, one block per (request, KV head[, split]); same workspace layout
-// and reduce kernel as launch_attn_decode.
+// ---- k_attn_decode_gqa.hip --------------------------------------------------------------------
+// grouped-query decode (4 <= H/Hkv <= 16): MFMA kernel, one block per (request, KV head[, split]); same workspace layout
+// and reduce kernel as launch_attn_decode.  t0 / t1: optional start / stop events of the kernel's own dispatch packet.
+bool attn_decode_gqa_supported(int quant_bit, int H, int Hkv, int D);
 hipError_t launch_attn_decode_gqa(hipStream_t s, const uint16_t* qkv, const KvAddr& kv, int quant_bit,
                                   const int64_t* seq_starts, const int64_t* start_pos, const int64_t* cache_indices,
                                   int64_t max_pages, int64_t nb, int H, int Hkv, int D, int split, float* workspace,
-                                  uint16_t* out);
+                                  uint16_t* out, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 
 // ---- k_gemm.hip -------------------------------------------------------------------------------
 // y[M,N] = x[M,K] . W[N,K]^T (+ per-channel / per-group scales).  wq_bit 0/8/4.  out_fp32: y is float.

@@ -267,11 +267,12 @@ void prof_end(Rank& R, ProfEvent* ev) {
 int decode_split(const pplhip_ctx* c, int64_t nb, int64_t max_kv_len) {
     const int mode = c->o.decoding_attn_split_k;
     if (mode == 0) return 1;
-    const int grp = c->H / c->Hkv;
-    const int64_t blocks = nb * ((grp >= 4 && grp <= 16) ? c->Hkv : c->H);  // GQA kernel: one block per KV head
+    const bool gqa = attn_decode_gqa_supported(c->d.cache_quant_bit, c->H, c->Hkv, c->D);
+    const int64_t blocks = nb * (gqa ? c->Hkv : c->H);  // GQA kernel: one block per KV head
     int split = 1;
-    // measured (profiles/attn_microbench.py): 512 workgroups already stream at 5.3 TB/s; split only below ~256
-    if (mode == 2 || (blocks < 256 && max_kv_len >= 512)) {
+    // measured (profiles/attn_microbench.py): 512 workgroups already stream at 5.3 TB/s; split only below ~256.  The grouped-query
+    // kernel's blocks are 8 waves with 70 KiB of LDS, two per CU: it wants all 512 slots filled (70B / TP8: 256 requests x 1 head)
+    if (mode == 2 || (blocks < (gqa ? 512 : 256) && max_kv_len >= 512)) {
         int64_t want = (512 + blocks - 1) / blocks;            // aim for >= 512 workgroups
         int64_t cap = std::max<int64_t>(1, max_kv_len / 256);  // >= 256 tokens per split
         split = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want, cap), 32));
@@ -296,7 +297,14 @@ int p2p_unavailable(pplhip_ctx* c, int rank, const std::string& why) {
 // the other processes (whose self-test kernels give up waiting for it after the bounded spin) do not wait in the all-reduce forever.
 int p2p_selftest(pplhip_ctx* c, const std::string* local_failure = nullptr) {
     const int n = (int)c->ranks.size(), tp = c->tp, hd = c->d.hidden_dim;
-    const int64_t cnt = std::min<int64_t>((int64_t)1 << 20, c->ranks[0].cap_T * (int64_t)hd) / 4 * 4;
+    // granules of the direct kernels (k_comm.hip): 16-byte pieces of the fp16 partial sums, 8- or 16-byte pieces of a shard's fp32
+    // logits rows; a model that does not fit them keeps RCCL instead of failing at its first real step
+    std::string shape_failure;
+    if (!local_failure && (c->vocab_local % 2 != 0 || hd % 8 != 0)) {
+        shape_failure = "vocab/tp must be even and hidden a multiple of 8 (vocab_local " + std::to_string(c->vocab_local) + ", hidden " + std::to_string(hd) + ")";
+        local_failure = &shape_failure;
+    }
+    const int64_t cnt = std::min<int64_t>((int64_t)1 << 20, c->ranks[0].cap_T * (int64_t)hd) / 8 * 8;
     // the gather test: every rank's [grows, gcols] fp32 block -> [grows, gcols * tp]
     const int64_t gcols = c->vocab_local / 2 * 2, grows = std::min<int64_t>(c->ranks[0].cap_B, std::max<int64_t>(1, ((int64_t)1 << 18) / gcols));
     const int64_t gcnt = grows * gcols;
@@ -380,7 +388,17 @@ int p2p_selftest(pplhip_ctx* c, const std::string* local_failure = nullptr) {
             if (!v && ok) { ok = false; why = "another rank failed its self-test"; }
         }
     }
-    if (!ok) return p2p_unavailable(c, 0, "self-test: " + why);
+    if (!ok) {
+        // the check loop stopped at the first rank that showed a failure: drain EVERY local rank (the others normally time out on
+        // the same dead peer) and clear every status word, or the RCCL steps that follow would report a stale "timed out"
+        for (int r = 0; r < n; ++r) {
+            Rank& R = c->ranks[r];
+            (void)hipSetDevice(R.device);
+            (void)hipStreamSynchronize(R.stream);
+            if (R.p2p_status) *R.p2p_status = 0;
+        }
+        return p2p_unavailable(c, 0, "self-test: " + why);
+    }
     c->comm_mode = 2;
     if (getenv("PPLHIP_VERBOSE")) fprintf(stderr, "[pplhip] direct collectives over peer-mapped memory: self-test passed on %d local rank(s) of %d\n", n, tp);
     return 0;
@@ -409,7 +427,7 @@ int p2p_connect_local(pplhip_ctx* c) {
 // a kernel of the direct path gave up waiting for a peer: surfaced at the step's synchronisation points
 int p2p_check(pplhip_ctx* c, int rank) {
     Rank& R = c->ranks[rank];
-    if (R.p2p_status && *R.p2p_status) {
+    if (c->comm_mode == 2 && R.p2p_status && *R.p2p_status) {
         const uint32_t v = *R.p2p_status;
         return fail(c, rank, PPLHIP_DEVICE_RUNTIME_ERROR, "direct collective timed out waiting for rank " + std::to_string((v - 1) & 15) +
                     ((v - 1) & 16 ? " (end barrier)" : " (start barrier)"));
@@ -1528,6 +1546,12 @@ int pplhip_profile_get(pplhip_ctx* c, int rank, int cls, int64_t* launches, doub
         }
     if (launches) *launches = n;
     if (total_ms) *total_ms = ms;
+    return 0;
+}
+
+int pplhip_profile_mode(pplhip_ctx* c, int mode) {
+    if (!c || mode < 0 || mode > 2) return PPLHIP_INVALID_VALUE;
+    c->o.enable_profiling = mode;
     return 0;
 }
 

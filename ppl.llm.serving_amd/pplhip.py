@@ -76,7 +76,7 @@ SYMBOLS = [
     "pplhip_last_error", "pplhip_rank_load", "pplhip_rank_set_tensor", "pplhip_rank_init_synthetic",
     "pplhip_kv_block_bytes", "pplhip_kv_capacity", "pplhip_kv_alloc", "pplhip_kv_ptrs", "pplhip_kv_read",
     "pplhip_kv_write", "pplhip_kv_fill_synthetic", "pplhip_set_inputs", "pplhip_run", "pplhip_debug_run_dump", "pplhip_logits", "pplhip_copy_logits", "pplhip_sync",
-    "pplhip_sample", "pplhip_penalty", "pplhip_profile_reset", "pplhip_profile_get", "pplhip_mem_info",
+    "pplhip_sample", "pplhip_penalty", "pplhip_profile_reset", "pplhip_profile_get", "pplhip_profile_mode", "pplhip_mem_info",
     "pplhip_op_embedding", "pplhip_op_rmsnorm", "pplhip_op_linear", "pplhip_op_linear_swiglu", "pplhip_op_rmsnorm_quant", "pplhip_op_quant_act", "pplhip_op_quant_weight",
     "pplhip_op_linear_i8", "pplhip_op_silu_mul", "pplhip_op_rope_kv_write",
     "pplhip_op_attention", "pplhip_build_rope_table",
@@ -123,6 +123,7 @@ def lib():
         L.pplhip_penalty.argtypes = [vp, vp, C.POINTER(PenaltyArgs)]
         L.pplhip_profile_reset.argtypes = [vp, C.c_int]
         L.pplhip_profile_get.argtypes = [vp, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(C.c_double)]
+        L.pplhip_profile_mode.argtypes = [vp, C.c_int]
         L.pplhip_mem_info.argtypes = [vp, C.c_int, C.POINTER(u64), C.POINTER(u64)]
         L.pplhip_op_embedding.argtypes = [vp, vp, vp, i64, i32, vp]
         L.pplhip_op_rmsnorm.argtypes = [vp, vp, vp, vp, f32, i64, i32, vp, vp]
@@ -349,6 +350,9 @@ class Context:
         n, ms = C.c_int64(), C.c_double()
         self._ck(lib().pplhip_profile_get(self.h, rank, cls, C.byref(n), C.byref(ms)), rank, "profile_get")
         return n.value, ms.value
+
+    def profile_mode(self, mode):
+        self._ck(lib().pplhip_profile_mode(self.h, mode), 0, "profile_mode")
 
     def mem_info(self, rank=0):
         f, t = C.c_uint64(), C.c_uint64()

@@ -62,8 +62,42 @@ def traffic(fetch_db, write_db, out_json, batch, kv_first, kv_last, layers, warm
     json.dump(out, open(out_json, "w"), indent=1)
 
 
+def pmc_series(db, kernel_substr, counter):
+    cur = sqlite3.connect(db).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)").fetchall()]
+    order = "dispatch_id" if "dispatch_id" in cols else ("id" if "id" in cols else "rowid")
+    return [r[0] for r in cur.execute(f"select value from counters_collection where kernel_name like ? and counter_name = ? order by {order}",
+                                      (f"%{kernel_substr}%", counter)).fetchall()]
+
+
+def traffic_table(fetch_db, write_db, out_json, model, batch, kv_len, layers, total_steps, label):
+    """profiles/attn_decode_traffic.json (round 3 format): HBM bytes per decode-attention launch BY KV LENGTH.  Step i of
+    `bench.py --kv-len K` (warm-up included) launches the kernel `layers` times at kv length K + i + 1; the table holds the mean
+    over those launches of 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes; gfx950 counts a 128-B read request as 64 B for 16 B/lane
+    coalesced reads, MI355X_MICROARCH.md HBM section), so bench.py can quote the traffic of whichever steps it timed."""
+    import json
+    batch, kv_len, layers, total_steps = map(int, (batch, kv_len, layers, total_steps))
+    f, w = pmc_series(fetch_db, "attn_decode_kernel", "FETCH_SIZE"), pmc_series(write_db, "attn_decode_kernel", "WRITE_SIZE")
+    n = min(len(f), len(w)) // layers
+    table = {}
+    for i in range(min(n, total_steps)):
+        fs, ws = f[i * layers:(i + 1) * layers], w[i * layers:(i + 1) * layers]
+        table[str(kv_len + i + 1)] = int(2 * 1024 * sum(fs) / len(fs) + 1024 * sum(ws) / len(ws))
+    out = {"round": 3, "kernel": "pplhip::attn_decode_kernel<8,128>", "label": label, "model": model, "batch": batch, "kv_quant": 8,
+           "cache_mode": 0, "dispatches": {"FETCH_SIZE": len(f), "WRITE_SIZE": len(w)}, "layers": layers,
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only; profiles/collect_r03.sh) of "
+                     "`python bench.py --steps 24 --warmup 3` -- a superset of the driver's --steps 20 --warmup 5 and of the defaults",
+           "source_short": f"profiles/attn_decode_traffic.json ({label}; PMC FETCH_SIZE x2 + WRITE_SIZE per dispatch, mean per kv length)",
+           "correction": "gfx950: FETCH_SIZE counts a 128-B request as 64 B for wide (16 B/lane) coalesced reads, so it is doubled "
+                         "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE used as is",
+           "hbm_bytes_per_launch_by_kv_len": table}
+    json.dump(out, open(out_json, "w"), indent=1)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "traffic":
         traffic(*sys.argv[2:])
+    elif sys.argv[1] == "traffic_table":
+        traffic_table(*sys.argv[2:])
     else:
         {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])

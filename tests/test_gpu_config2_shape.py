@@ -1,0 +1,179 @@
+"""BASELINE config 2 at ITS OWN launch shape: the operators of a LLaMA-2-7B W8A16 decode step at
+running batch 1024 -- the shape bench.py times, which until round 3 no test asserted anything about.
+
+  * decode attention: B = 1024 requests, H = Hkv = 32, D = 128, int8-g8 KV, kv lengths 400..600, one layer of a
+    560 000-token slab in cache layout 3 (so the V half starts beyond 2^31 elements and the slots of the batch are spread
+    over 4.6 GB: the (32, 1024, 1) grid, the 64-bit slot arithmetic and the streaming loads at full size), contiguous slots
+    and 16-token pages handed out in shuffled order -- against ref_attention on every row;
+  * the four layer GEMMs at M = 1024 (wqkv 12288 x 4096, wo 4096 x 4096, w13 22016 x 4096 with the fused SwiGLU epilogue,
+    w2 4096 x 11008): the 128 x 128 tile kernels with whole 8-tile row blocks -- against ref_linear_raw on sampled rows (first
+    / last rows of a tile, tile seams, random ones)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import ref
+from tests.conftest import load_pplhip
+from tests.parity import record_err
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+B, H, D = 1024, 32, 128
+N_SLAB = 560_000
+PAGE = 16
+
+
+def f16(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float16)
+
+
+def tiled(n, block):
+    out = np.empty(n, dtype=block.dtype)
+    for off in range(0, n, block.size):
+        k = min(block.size, n - off)
+        out[off:off + k] = block[:k]
+    return out
+
+
+@pytest.fixture(scope="module")
+def slab():
+    """one layer of int8-g8 KV history for 560 000 tokens (4.6 GB + 1.1 GB of scales), host and device"""
+    rng = np.random.RandomState(2)
+    elems = N_SLAB * 2 * H * D
+    # blocks of a size that is NOT a multiple of a token row, so that neighbouring tokens and heads hold different bytes
+    cache = tiled(elems, rng.randint(-127, 128, size=(1 << 24) + 4099).astype(np.int8))
+    scale = tiled(elems // 8, f16(0.02 * (0.5 + rng.rand((1 << 21) + 1031))))
+    dcache = torch.from_numpy(cache).cuda()
+    dscale = torch.from_numpy(scale).cuda()
+    yield cache, scale, dcache, dscale
+    del dcache, dscale
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_decode_attention_batch_1024_over_a_560k_token_slab(slab, mode):
+    m = load_pplhip()
+    cache, scale, dcache, dscale = slab
+    rng = np.random.RandomState(40 + mode)
+    kv = rng.randint(400, 601, size=B).astype(np.int64)                   # kv length INCLUDING the current token
+    start = kv - 1
+    desc = ref.make_desc(hidden_dim=H * D, intermediate_dim=64, num_layers=1, num_heads=H, num_kv_heads=H, vocab_size=64,
+                         cache_quant_bit=8, cache_quant_group=8, cache_layout=3, cache_mode=mode, page_size=PAGE if mode else 0)
+    if mode == 0:
+        # ragged ranges in shuffled order over the whole slab: request b starts wherever the allocator put it
+        order = rng.permutation(B)
+        starts = np.concatenate([[0], np.cumsum(kv[order] + rng.randint(0, 40, size=B))[:-1]])
+        starts = starts + (N_SLAB - (starts[-1] + 601))                    # right-aligned: the last range ends at the slab's end
+        cache_idx = np.empty(B, dtype=np.int64)
+        cache_idx[order] = starts
+        assert cache_idx.min() >= 0 and (cache_idx + kv).max() <= N_SLAB
+        max_pages = 0
+    else:
+        npg = (kv + PAGE - 1) // PAGE
+        max_pages = int(npg.max())
+        pages = rng.permutation(N_SLAB // PAGE)
+        cache_idx = np.full((B, max_pages), np.iinfo(np.int64).max, dtype=np.int64)
+        k = 0
+        for b in range(B):
+            cache_idx[b, :npg[b]] = pages[k:k + npg[b]]
+            k += npg[b]
+        assert int(cache_idx[cache_idx < N_SLAB].max()) * PAGE > 500_000   # pages from the far end of the slab are in use
+    seq = np.arange(B + 1, dtype=np.int64)
+    qkv = f16(rng.randn(B, 3 * H * D))
+    rope = np.empty((1024, D), dtype=np.float32)
+    ref.lib().ref_build_rope_table(rope.ctypes.data, 1024, D, 10000.0)
+    # the current token's K/V go through the oracle's RoPE + quantising write into the HOST slab; the same bytes are then
+    # patched into the device slab (rows of 128 B / 32 B at the token's slot, per head, K and V)
+    q32 = qkv.astype(np.float32)
+    ref.lib().ref_rope_kv_write(q32.ctypes.data, rope.ctypes.data, C.byref(desc), H, H, D, 0, cache.ctypes.data, scale.ctypes.data,
+                                N_SLAB, seq.ctypes.data, start.ctypes.data, cache_idx.ctypes.data, max_pages, B)
+    if mode == 0:
+        slots = cache_idx + start
+    else:
+        slots = cache_idx[np.arange(B), start // PAGE] * PAGE + start % PAGE
+    c4 = cache.reshape(2, H, N_SLAB, D)
+    s4 = scale.reshape(2, H, N_SLAB, D // 8)
+    ds = torch.from_numpy(slots).cuda()
+    dcache.view(2, H, N_SLAB, D)[:, :, ds] = torch.from_numpy(np.ascontiguousarray(c4[:, :, slots])).cuda()
+    dscale.view(2, H, N_SLAB, D // 8)[:, :, ds] = torch.from_numpy(np.ascontiguousarray(s4[:, :, slots])).cuda()
+    want = np.zeros((B, H * D), dtype=np.float32)
+    ref.lib().ref_attention(q32.ctypes.data, C.byref(desc), H, H, D, 0, cache.ctypes.data, scale.ctypes.data, N_SLAB,
+                            seq.ctypes.data, start.ctypes.data, cache_idx.ctypes.data, max_pages, B, want.ctypes.data)
+    v = m.KvView()
+    v.cache, v.scale = dcache.data_ptr(), dscale.data_ptr()
+    v.max_tokens, v.num_layers, v.kv_heads, v.head_dim = N_SLAB, 1, H, D
+    v.quant_bit, v.quant_group, v.layout, v.mode, v.page_size, v.layer = 8, 8, 3, mode, PAGE if mode else 0, 0
+    dq = torch.from_numpy(q32.astype(np.float16)).cuda()
+    dseq, dsp, dci = torch.from_numpy(seq).cuda(), torch.from_numpy(start).cuda(), torch.from_numpy(cache_idx).cuda()
+    out = torch.zeros((B, H * D), dtype=torch.float16, device="cuda")
+    rc = m.lib().pplhip_op_attention(None, dq.data_ptr(), C.byref(v), dseq.data_ptr(), dsp.data_ptr(), dci.data_ptr(), max_pages, B, B,
+                                     B, 1, int(kv.max()), H, 1, None, 0, out.data_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    err = np.abs(got - want)
+    vmax = 0.03 * 127
+    record_err(f"config2_attn_decode_b1024_mode{mode}", float(err.max()) / vmax, 1.5e-3)
+    assert (err <= 1.5e-3 + 1.5e-3 * np.abs(want)).all(), (float(err.max()), int((err > 1.5e-3 + 1.5e-3 * np.abs(want)).sum()))
+
+
+SAMPLE_ROWS = np.array(sorted(set([0, 1, 15, 16, 63, 64, 127, 128, 129, 255, 256, 511, 512, 640, 767, 895, 896, 1022, 1023] +
+                                  list(np.random.RandomState(3).randint(0, 1024, size=13)))))
+
+
+@pytest.mark.parametrize("name,N,K", [("wqkv", 12288, 4096), ("wo", 4096, 4096), ("w2", 4096, 11008)])
+def test_layer_gemm_at_batch_1024(name, N, K):
+    m = load_pplhip()
+    rng = np.random.RandomState(N + K)
+    M = 1024
+    x = f16(rng.randn(M, K) * 0.5)
+    w = rng.randint(-127, 128, size=(N, K)).astype(np.int8)
+    sc = f16(0.0003 * (0.5 + rng.rand(N)))
+    dx, dw, dsc = torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda(), torch.from_numpy(sc).cuda()
+    y = torch.empty((M, N), dtype=torch.float16, device="cuda")
+    assert m.lib().pplhip_op_linear(None, dx.data_ptr(), dw.data_ptr(), dsc.data_ptr(), 8, 0, M, N, K, y.data_ptr(), 0) == 0
+    torch.cuda.synchronize()
+    got = y.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    xs = np.ascontiguousarray(x[SAMPLE_ROWS].astype(np.float32))
+    want = np.empty((len(SAMPLE_ROWS), N), dtype=np.float32)
+    ref.lib().ref_linear_raw(xs.ctypes.data, w.ctypes.data, sc.ctypes.data, 8, 0, len(SAMPLE_ROWS), N, K, want.ctypes.data, 0)
+    err = np.abs(got[SAMPLE_ROWS] - want)
+    mag = float(np.abs(want).max())
+    record_err(f"config2_gemm_{name}_m1024", float(err.max()) / mag, 1.5e-3)
+    tol = 1.5e-3 * np.abs(want) + 1.5e-3 * 0.05 * mag + 1e-5               # the tolerance of tests/test_gpu_ops.py::test_linear
+    assert (err <= tol).all(), (float(err.max()), mag, int((err > tol).sum()))
+    # accumulation-order noise only: almost every element is the oracle's fp16 number bit for bit
+    assert (got[SAMPLE_ROWS] == want).mean() > 0.97
+
+
+def test_w13_gemm_with_fused_swiglu_at_batch_1024():
+    m = load_pplhip()
+    rng = np.random.RandomState(77)
+    M, inter, K = 1024, 11008, 4096
+    N = 2 * inter
+    x = f16(rng.randn(M, K) * 0.5)
+    w = rng.randint(-127, 128, size=(N, K)).astype(np.int8)
+    sc = f16(0.0003 * (0.5 + rng.rand(N)))
+    perm = np.empty(N, dtype=np.int64)                                     # device layout: rows interleaved (gate_i, up_i)
+    perm[0::2], perm[1::2] = np.arange(inter), inter + np.arange(inter)
+    dx = torch.from_numpy(x).cuda()
+    dw, dsc = torch.from_numpy(np.ascontiguousarray(w[perm])).cuda(), torch.from_numpy(np.ascontiguousarray(sc[perm])).cuda()
+    y = torch.empty((M, inter), dtype=torch.float16, device="cuda")
+    assert m.lib().pplhip_op_linear_swiglu(None, dx.data_ptr(), dw.data_ptr(), dsc.data_ptr(), 8, 0, M, N, K, y.data_ptr()) == 0
+    torch.cuda.synchronize()
+    got = y.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    R = len(SAMPLE_ROWS)
+    xs = np.ascontiguousarray(x[SAMPLE_ROWS].astype(np.float32))
+    gu = np.empty((R, N), dtype=np.float32)
+    ref.lib().ref_linear_raw(xs.ctypes.data, w.ctypes.data, sc.ctypes.data, 8, 0, R, N, K, gu.ctypes.data, 0)
+    want = np.empty((R, inter), dtype=np.float32)
+    ref.lib().ref_silu_mul(gu.ctypes.data, R, inter, want.ctypes.data)
+    err = np.abs(got[SAMPLE_ROWS] - want)
+    mag = float(np.abs(want).max())
+    record_err("config2_gemm_w13_swiglu_m1024", float(err.max()) / mag, 3e-3)
+    tol = 3e-3 * np.abs(want) + 3e-3 * 0.05 * mag + 1e-5                   # two fp16 roundings upstream of the product (test_gpu_ops.py)
+    assert (err <= tol).all(), (float(err.max()), mag, int((err > tol).sum()))

@@ -19,7 +19,7 @@ import pytest
 
 from oracle import ref
 from tests.conftest import load_pplhip
-from tests.parity import record_err
+from tests.parity import oracle_noise, record_err
 from tests.test_oracle_hf import desc_from_meta, load_fixture
 
 pytestmark = pytest.mark.gpu
@@ -59,12 +59,13 @@ def generate_both(m, ctx, models, desc, prompts, steps, max_tokens):
         st_r = ref.make_step(tok, seq_starts, start_pos, cache_idx, dec, max_pages)
         st_g = m.make_step(tok, seq_starts, start_pos, cache_idx, dec, max_pages, req_list_changed=1 if s == 0 else 0)
         want = ref.forward(models, st_r)
+        alt = oracle_noise(models, st_r)
         ctx.set_inputs(0, st_g)
         ctx.run(0)
         gtok, glp = ctx.sample(n, top_k=1)
         got = ctx.copy_logits(n)
         wtok, wlp = ref.sample(want, top_k=1)
-        res.append((got, want, gtok, wtok, glp, wlp))
+        res.append((got, want, gtok, wtok, glp, wlp, alt))
         start_pos = start_pos + (seq_starts[1:] - seq_starts[:-1])
         tok = wtok.astype(np.int64)
         seq_starts = np.arange(n + 1)
@@ -74,10 +75,10 @@ def generate_both(m, ctx, models, desc, prompts, steps, max_tokens):
 def check_steps(res, k, name=None):
     if name is None:
         name = os.environ.get("PYTEST_CURRENT_TEST", "?").split("::")[-1].split(" ")[0]
-    for s, (got, want, gtok, wtok, glp, wlp) in enumerate(res):
+    for s, (got, want, gtok, wtok, glp, wlp, alt) in enumerate(res):
         tol = 1e-3 * k * max(1.0, np.abs(want).max())
         err = np.abs(got - want).max()
-        record_err(name, err / max(1.0, np.abs(want).max()), 1e-3 * k)
+        record_err(name, err / max(1.0, np.abs(want).max()), 1e-3 * k, noise=np.abs(alt - want).max() / max(1.0, np.abs(want).max()))
         assert err <= tol, (s, err, tol)
         srt = np.sort(want, -1)
         safe = (srt[:, -1] - srt[:, -2]) > 2 * tol

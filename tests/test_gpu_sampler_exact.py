@@ -5,7 +5,7 @@ one default value, then one per row, every step) and hands them to sample_topk_t
 same way, in-process, so the test restarts the generator (srand) through ctypes, replays rand() in Python to learn the
 numbers the library will draw next, restarts it again, samples on the device, and feeds the oracle (ref.sample(rnd=...)) the
 replayed numbers.  Tokens must be EQUAL on every row whose decision is not a cumulative-mass tie: the device accumulates
-in fp32, the oracle in fp64, so a row whose target (rand * kept mass) or whose top-p boundary lies within 1e-5 of a
+in fp32, the oracle in fp64, so a row whose target (rand * kept mass) or whose top-p boundary lies within 3e-6 of a
 cumulative-mass edge may legitimately land on the neighbouring candidate; such rows are counted, not compared."""
 import ctypes as C
 
@@ -79,13 +79,13 @@ def test_stochastic_sampling_is_token_exact_vs_oracle(top_k, top_p, with_tempera
         for b in range(B):
             x = logits[b] / (temps[b] if temps is not None else np.float32(1.0))
             t64, margin = decision_margins(x, top_k, top_p, rnds[s][b])
-            if margin < 1e-5:
+            if margin < 3e-6:
                 tied += 1
                 continue
             assert wtok[b] == t64, (s, b)                                  # the oracle agrees with the fp64 restatement
             assert tok[b] == wtok[b], (s, b, int(tok[b]), int(wtok[b]), float(rnds[s][b]))
             assert abs(lp[b] - wlp[b]) < 2e-4
-    assert tied <= 0.02 * steps * B, tied
+    assert tied <= 0.04 * steps * B, tied
     ctx.close()
 
 
@@ -113,7 +113,7 @@ def test_per_row_top_p_list_and_q3_temperatures_only_on_changed_steps():
         for b in range(B):
             x = logits[b] / (temps[b] if changed else np.float32(1.0))
             _, margin = decision_margins(x, 40, float(topp[b]) if changed else 0.6, rnds[s][b])
-            if margin < 1e-5:
+            if margin < 3e-6:
                 continue
             n_cmp += 1
             assert tok[b] == wtok[b], (s, b)
@@ -137,7 +137,7 @@ def test_full_vocabulary_sampling_top_p_one():
     same = 0
     for b in range(B):
         _, margin = decision_margins(logits[b], 0, 1.0, rnds[0][b])
-        if margin >= 1e-5:
+        if margin >= 3e-6:
             assert tok[b] == wtok[b], b
             same += 1
     assert same >= B - 2

@@ -16,7 +16,7 @@ import pytest
 
 from oracle import ref
 from tests.conftest import load_pplhip
-from tests.parity import record_err
+from tests.parity import oracle_noise, record_err
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -70,7 +70,9 @@ class Group:
             self.ctx.kv_write(r, 1, ks)
 
     def step(self, tok, seq_starts, start_pos, cache_idx, dec, max_pages, changed):
-        want = ref.forward(self.models, ref.make_step(tok, seq_starts, start_pos, cache_idx, dec, max_pages))
+        st_r = ref.make_step(tok, seq_starts, start_pos, cache_idx, dec, max_pages)
+        want = ref.forward(self.models, st_r)
+        self.last_alt = oracle_noise(self.models, st_r)
         st = self.m.make_step(tok, seq_starts, start_pos, cache_idx, dec, max_pages, req_list_changed=changed)
         for r in range(self.tp):      # one host thread enqueues every rank's step; the streams run side by side
             self.ctx.set_inputs(r, st)
@@ -116,7 +118,7 @@ def generate(g, prompts, steps, start=None):
     out = []
     for s in range(steps):
         got, want, gtok = g.step(tok, seq, start_pos, cache_idx, 0 if s == 0 else n, mp, 1 if s == 0 else 0)
-        out.append((got, want, gtok))
+        out.append((got, want, gtok, g.last_alt))
         start_pos = start_pos + (seq[1:] - seq[:-1])
         tok = want.argmax(-1).astype(np.int64)
         seq = np.arange(n + 1)
@@ -124,16 +126,17 @@ def generate(g, prompts, steps, start=None):
 
 
 def check(name, res, k):
-    worst = 0.0
-    for s, (got, want, gtok) in enumerate(res):
+    worst, noise = 0.0, 0.0
+    for s, (got, want, gtok, alt) in enumerate(res):
         scale = max(1.0, float(np.abs(want).max()))
         err = float(np.abs(got - want).max()) / scale
         worst = max(worst, err)
+        noise = max(noise, float(np.abs(alt - want).max()) / scale)
         assert err <= 1e-3 * k, (name, s, err)
         srt = np.sort(want, -1)
         safe = (srt[:, -1] - srt[:, -2]) > 2e-3 * k * scale
         assert (gtok[safe] == want.argmax(-1)[safe]).all(), (name, s)
-    record_err(name, worst, 1e-3 * k)
+    record_err(name, worst, 1e-3 * k, noise=noise)
 
 
 @pytest.mark.parametrize("tp", [2, 4, 8])
@@ -264,7 +267,7 @@ def test_llama70b_tp8_rank_slices_w4a16_decode_at_kv2048():
     start = kv - 1
     for s in range(2):
         got, want, gtok = g.step(tok, np.arange(n + 1), start, cache_idx, n, mp, 1 if s == 0 else 0)
-        res.append((got, want, gtok))
+        res.append((got, want, gtok, g.last_alt))
         tok = want.argmax(-1).astype(np.int64)
         start = start + 1
     check("llama70b_tp8_w4a16_decode_kv2048", res, k=6)   # observed 4.1e-3: grouped-query MFMA decode over int8 KV (see test_gpu_model.py)
