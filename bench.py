@@ -505,7 +505,7 @@ def main():
                                    f"..{args.kv_len + K + W}, greedy top_k=1, cache_layout 3 / cache_mode {args.cache_mode}, "
                                    f"kv int{args.kv_quant or 16}", "global_batch": B, "seq_len": 1024,
                        "parallelism": f"tp{world}", "layers": desc.num_layers, "collectives": comm_mode},
-            "roofline": {"kernel": "attn_decode_kernel<8,128>" if args.kv_quant else "attn_decode_kernel<0,128>",
+            "roofline": {"kernel": ("attn_decode_gqa_kernel" if 4 <= H // max(Hkv, 1) <= 16 else "attn_decode_kernel") + f"<{args.kv_quant},{D}>",
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "launches": n_attn, "avg_launch_ms": round(ms_attn / max(n_attn, 1), 4),

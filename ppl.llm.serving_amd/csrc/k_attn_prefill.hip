@@ -289,15 +289,22 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
                 }
             }
             // ---- O += P . V : A = P (this lane's 8 keys per k-step: tiles 2s, 2s+1), B = V^T from LDS ---------
+            // P enters the MFMA as an exact pair of fp16 numbers, hi = fp16(p) and lo = fp16(p - hi) (22 significant bits, two
+            // MFMAs): with P rounded to fp16 alone the output differed from the oracle's by one fp16 ulp on a third of its
+            // elements (twice the oracle's own summation-order noise on the HF fixtures, tests/test_gpu_model.py)
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) {
-                h8 pa[RG];
+                h8 pa[RG], pl[RG];
 #pragma unroll
                 for (int g = 0; g < RG; ++g)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        pa[g][r] = to_h(sacc[g][2 * s2][r]);
-                        pa[g][4 + r] = to_h(sacc[g][2 * s2 + 1][r]);
+                        const float p0 = sacc[g][2 * s2][r], p1 = sacc[g][2 * s2 + 1][r];
+                        const _Float16 h0 = to_h(p0), h1 = to_h(p1);
+                        pa[g][r] = h0;
+                        pa[g][4 + r] = h1;
+                        pl[g][r] = to_h(p0 - (float)h0);
+                        pl[g][4 + r] = to_h(p1 - (float)h1);
                     }
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
@@ -305,7 +312,10 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
                     const uint2 hi = v_frag_tr(Vs, (2 * s2 + 1) * DT + dt, kq, l15);
                     const h8 bv = __builtin_bit_cast(h8, make_uint4(lo.x, lo.y, hi.x, hi.y));
 #pragma unroll
-                    for (int g = 0; g < RG; ++g) o[g][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa[g], bv, o[g][dt], 0, 0, 0);
+                    for (int g = 0; g < RG; ++g) {
+                        o[g][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl[g], bv, o[g][dt], 0, 0, 0);
+                        o[g][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa[g], bv, o[g][dt], 0, 0, 0);
+                    }
                 }
             }
         }

@@ -270,9 +270,10 @@ int decode_split(const pplhip_ctx* c, int64_t nb, int64_t max_kv_len) {
     const bool gqa = attn_decode_gqa_supported(c->d.cache_quant_bit, c->H, c->Hkv, c->D);
     const int64_t blocks = nb * (gqa ? c->Hkv : c->H);  // GQA kernel: one block per KV head
     int split = 1;
-    // measured (profiles/attn_microbench.py): 512 workgroups already stream at 5.3 TB/s; split only below ~256.  The grouped-query
-    // kernel's blocks are 8 waves with 70 KiB of LDS, two per CU: it wants all 512 slots filled (70B / TP8: 256 requests x 1 head)
-    if (mode == 2 || (blocks < (gqa ? 512 : 256) && max_kv_len >= 512)) {
+    // measured (profiles/attn_microbench.py): 512 workgroups already stream at 5.3 TB/s; split only below ~256.  (The grouped-query
+    // kernel at 256 blocks -- 70B / TP8, 256 requests x 1 KV head -- is faster unsplit: 37 us against 46 us with split 2, the reduce
+    // launch costs more than the second block per CU brings, profiles/r03_roofline_sweep.json)
+    if (mode == 2 || (blocks < 256 && max_kv_len >= 512)) {
         int64_t want = (512 + blocks - 1) / blocks;            // aim for >= 512 workgroups
         int64_t cap = std::max<int64_t>(1, max_kv_len / 256);  // >= 256 tokens per split
         split = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want, cap), 32));

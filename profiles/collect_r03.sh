@@ -1,0 +1,62 @@
+#!/bin/bash
+# Round-3 evidence, collected on the GPU box from the repo root:  bash profiles/collect_r03.sh [part ...]   (default: all parts)
+#  bench    the bench.py line, default flags and the driver's flags (--steps 20 --warmup 5)   -> gpurun_out/r03_bench{,_driver}.json
+#  stats    rocprofv3 --kernel-trace --stats of the same command                              -> gpurun_out/r03_kernel_stats.csv
+#  pmc      PMC passes FETCH_SIZE / WRITE_SIZE (separate runs, --kernel-trace only) of `bench.py --steps 24 --warmup 3` (a superset
+#           of the driver's and the default kv lengths) -> r03_attn_decode_pmc_{fetch,write}.csv, attn_decode_traffic.json (per kv length)
+#  sq       SQ counters of the GEMMs (MFMA busy)                                              -> gpurun_out/r03_gemm_w8_pmc.csv
+#  sweep    SURVEY D2 fixed-shape decode-attention sweep                                      -> gpurun_out/r03_roofline_sweep.json
+#  config5  benchmark_prefix_cache_offline, 64 x 8192-token prompts sharing 6144 tokens      -> gpurun_out/r03_prefix_cache_benchmark.log
+#  tp       per-rank compute of the tensor-parallel configurations, identity collectives      -> gpurun_out/r03_tp_emulation.txt
+# Summaries are copied into profiles/ by hand (gpurun_out/ is scratch).
+set -u
+R=$GRAFT_REPO_ROOT
+PARTS=${*:-bench stats pmc sq sweep config5 tp}
+mkdir -p $R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+LEAN="--no-cpu-baseline --no-serving-leg --no-i8i8-leg --prefill-sample 0"
+for part in $PARTS; do case $part in
+bench)
+  python $R/bench.py 2>$R/gpurun_out/r03_bench.err > $R/gpurun_out/r03_bench.json
+  python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-serving-leg --no-i8i8-leg 2>/dev/null > $R/gpurun_out/r03_bench_driver_flags.json
+  python $R/bench.py --breakdown $LEAN --ragged-steps 0 2>/dev/null > $R/gpurun_out/r03_bench_breakdown.json ;;
+stats)
+  rm -rf /tmp/prof_stats
+  timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -- python $R/bench.py $LEAN > /tmp/prof_stats.log 2>&1
+  db=$(find /tmp/prof_stats -name "*.db" | head -1)
+  [ -n "$db" ] && python $R/profiles/summarize_rocpd.py stats $db $R/gpurun_out/r03_kernel_stats.csv ;;
+pmc)
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/prof_$c
+    timeout 1200 rocprofv3 --pmc $c --kernel-trace -d /tmp/prof_$c -- python $R/bench.py $LEAN --ragged-steps 0 --breakdown-steps 0 --steps 24 --warmup 3 > /tmp/prof_$c.log 2>&1
+  done
+  dbf=$(find /tmp/prof_FETCH_SIZE -name "*.db" | head -1); dbw=$(find /tmp/prof_WRITE_SIZE -name "*.db" | head -1)
+  [ -n "$dbf" ] && python $R/profiles/summarize_rocpd.py pmc $dbf $R/gpurun_out/r03_attn_decode_pmc_fetch.csv
+  [ -n "$dbw" ] && python $R/profiles/summarize_rocpd.py pmc $dbw $R/gpurun_out/r03_attn_decode_pmc_write.csv
+  # kv_len 512, steps 0..26 (3 warm-up + 24 timed): step i launches the kernel 32 times at kv length 512 + i + 1
+  [ -n "$dbf" ] && [ -n "$dbw" ] && python $R/profiles/summarize_rocpd.py traffic_table $dbf $dbw $R/gpurun_out/attn_decode_traffic.json llama2-7b 1024 512 32 27 "HEAD round 3" ;;
+sq)
+  rm -rf /tmp/prof_sq
+  timeout 1200 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 --kernel-trace -d /tmp/prof_sq -- python $R/bench.py $LEAN --ragged-steps 0 --breakdown-steps 0 --steps 2 --warmup 1 > /tmp/prof_sq.log 2>&1
+  db=$(find /tmp/prof_sq -name "*.db" | head -1)
+  [ -n "$db" ] && python $R/profiles/summarize_rocpd.py pmc $db $R/gpurun_out/r03_gemm_w8_pmc.csv ;;
+sweep)
+  python $R/profiles/roofline_sweep.py $R/gpurun_out/r03_roofline_sweep.json > $R/gpurun_out/r03_roofline_sweep.log 2>&1 ;;
+config5)
+  cd $R/ppl.llm.serving_amd
+  ./build/benchmark_prefix_cache_offline --model-param-path configs/llama2_7b_w8a16_kv8_paged.json --synthetic-weights --enable-prefix-cache \
+     --max-prefill-batch 1 --max-input-tokens-per-request 8192 --max-total-tokens-per-request 16384 --batch 64 > $R/gpurun_out/r03_prefix_cache_benchmark.log 2>&1
+  ./build/benchmark_prefix_cache_offline --model-param-path configs/llama2_7b_w8a16_kv8_paged.json --synthetic-weights --enable-prefix-cache \
+     --max-prefill-batch 1 --max-input-tokens-per-request 8192 --max-total-tokens-per-request 16384 --batch 1 --second-run new-tails >> $R/gpurun_out/r03_prefix_cache_benchmark.log 2>&1
+  cd /tmp ;;
+tp)
+  OUT=$R/gpurun_out/r03_tp_emulation.txt
+  L="--no-cpu-baseline --no-serving-leg --no-i8i8-leg --prefill-sample 0 --ragged-steps 0 --breakdown"
+  fmt='import sys,json; r=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith("{")][-1]); print(sys.argv[1], r["ms_per_step"], r["breakdown_ms_per_step"], r["roofline"]["achieved"], r["roofline"]["kernel"])'
+  echo "# bench.py --emulate-tp N $L  (one rank's slice, identity collectives; columns: ms/step, breakdown, decode-attention algorithmic GB/s)" > $OUT
+  for tp in 2 4 8; do python $R/bench.py --emulate-tp $tp $L 2>/dev/null | python -c "$fmt" "7b_w8a16_b1024_kv512_tp$tp" >> $OUT; done
+  python $R/bench.py --model llama2-13b --batch 512 --kv-len 1024 --emulate-tp 2 $L 2>/dev/null | python -c "$fmt" "13b_w8a16_b512_kv1024_tp2(config3)" >> $OUT
+  python $R/bench.py --model llama2-70b --weight-quant 4 --batch 256 --kv-len 2048 --emulate-tp 8 $L 2>/dev/null | python -c "$fmt" "70b_w4a16_b256_kv2048_tp8(config4)" >> $OUT
+  python $R/bench.py --cache-mode 1 $L 2>/dev/null | python -c "$fmt" "7b_w8a16_b1024_kv512_tp1_paged16" >> $OUT ;;
+esac; done
+ls -la $R/gpurun_out | tail -25

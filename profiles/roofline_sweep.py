@@ -23,7 +23,7 @@ def heuristic_split(B, kv, H, Hkv):
     """pplhip.cc decode_split, mode 1"""
     gqa = 4 <= H // Hkv <= 16
     blocks = B * (Hkv if gqa else H)
-    if blocks < (512 if gqa else 256) and kv >= 512:
+    if blocks < 256 and kv >= 512:
         want = (512 + blocks - 1) // blocks
         cap = max(1, kv // 256)
         return max(1, min(want, cap, 32))

@@ -1,16 +1,20 @@
 """End-to-end parity of the decoder forward (pplhip_set_inputs / pplhip_run / pplhip_sample) against the CPU oracle
 and the HF golden vectors: packed ragged prefill, decode steps, all cache layouts/modes, fp16 and int8 KV,
-fp16 / W8A16 / W4A16 weights.  Tolerance on logits: |d| <= 1e-3 * k * max(1, |logit|max) (north star: "logits within
-1e-3 fp16", i.e. k = 1); greedy tokens exact wherever the oracle's top-2 margin exceeds the tolerance.
+fp16 / W8A16 / W4A16 weights.
 
-k is set per test from the errors the hardware actually produced (profiles/r02_parity_errors.jsonl; every comparison
-appends to that log through tests/parity.py), with ~1.5x headroom.  k = 1 holds for multi-head models with fp16 or
-W8A16 / W4A16 weights.  Documented causes of k > 1:
-  * int8-g8 KV (k 2): quantisation is discontinuous -- K/V inputs that differ from the oracle's by one fp16 rounding can
-    flip a cache byte by one LSB (test_hf_fixture_model checks <= 3 LSB on < 5 % of the bytes), and one flipped byte moves
-    a logit of these tiny models by ~1e-3 of the logit scale;
-  * grouped-query models (k 3; with int8 KV k 6): decode and prefill attention run on the MFMA, which takes the
-    probabilities and the dequantised K/V as fp16 (DESIGN.md numerics) where the oracle keeps fp32."""
+Tolerance on logits (round 3).  The north star asks for "logits within 1e-3 fp16".  Two CORRECT fp16 implementations of this
+specification do not always meet that between themselves: every model-level comparison here also runs the oracle a second time
+with its fp32 dot products summed in another order (tests/parity.py oracle_noise, ref.MODE_ALT_ORDER) and records how far the two
+oracles are apart -- the noise floor of the case (0.2e-3 .. 2e-3 on these tiny models, 1.3e-2 at 32 layers,
+tests/test_gpu_fulldepth.py).  The device must satisfy BOTH
+    |d| <= max(1e-3, NOISE_RATIO x noise floor) x max(1, |logit|max)      (no further from the oracle than ~2 oracles from each other)
+    |d| <= 1e-3 x k x max(1, |logit|max)                                  (a fixed cap per test, k from the observed errors)
+and greedy tokens must be equal wherever the oracle's top-2 margin exceeds twice the tolerance.  Observed errors and noise floors
+of every comparison: profiles/r03_parity_errors.jsonl.  Causes of the larger k:
+  * int8-g8 KV: quantisation is discontinuous -- K/V inputs that differ from the oracle's by one fp16 rounding can flip a cache
+    byte by one LSB (test_hf_fixture_model checks <= 3 LSB on < 5 % of the bytes), worth eight fp16 roundings;
+  * the prefill attention kernel feeds dequantised int8 K/V to the MFMA as fp16 (one rounding of q x scale; P is an exact hi + lo
+    pair since round 3, and the grouped-query decode kernel is exact in all three operands)."""
 import os
 import tempfile
 
@@ -24,6 +28,12 @@ from tests.test_oracle_hf import desc_from_meta, load_fixture
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
+# imported at collection time, before any device work: importing `transformers` (dozens of extension modules) late, from inside a
+# test of a process whose HIP runtime and OpenMP pools are already running, segfaulted intermittently (2 runs of 6, round 3)
+try:
+    from tests import test_export_hf as te
+except (Exception, pytest.skip.Exception):   # transformers missing
+    te = None
 
 
 def plan_cache(desc, lens_total, max_tokens, seed=0):
@@ -72,14 +82,20 @@ def generate_both(m, ctx, models, desc, prompts, steps, max_tokens):
     return res
 
 
+NOISE_RATIO = 2.5
+
+
 def check_steps(res, k, name=None):
     if name is None:
         name = os.environ.get("PYTEST_CURRENT_TEST", "?").split("::")[-1].split(" ")[0]
     for s, (got, want, gtok, wtok, glp, wlp, alt) in enumerate(res):
-        tol = 1e-3 * k * max(1.0, np.abs(want).max())
+        scale = max(1.0, np.abs(want).max())
+        noise = np.abs(alt - want).max() / scale
+        rel = min(1e-3 * k, max(1e-3, NOISE_RATIO * noise)) if noise > 0 else 1e-3 * k   # (integer GEMMs have no summation-order noise)
+        tol = rel * scale
         err = np.abs(got - want).max()
-        record_err(name, err / max(1.0, np.abs(want).max()), 1e-3 * k, noise=np.abs(alt - want).max() / max(1.0, np.abs(want).max()))
-        assert err <= tol, (s, err, tol)
+        record_err(name, err / scale, rel, noise=noise)
+        assert err <= tol, (s, err / scale, rel, noise)
         srt = np.sort(want, -1)
         safe = (srt[:, -1] - srt[:, -2]) > 2 * tol
         assert (gtok[safe] == wtok[safe]).all(), s
@@ -105,8 +121,8 @@ def test_hf_fixture_model(golden_dir, name, layout, mode, quant):
     ctx.kv_alloc(0, max_tokens)
     steps = hf_logits.shape[1]
     res = generate_both(m, ctx, [rm], desc, prompts, steps, max_tokens)
-    # observed (r02): mha 0.8e-3 / 1.2e-3 (fp16 / int8 KV), gqa 2.1e-3 / 4.2e-3
-    check_steps(res, k={("mha", 0): 1.5, ("mha", 8): 2, ("gqa", 0): 3, ("gqa", 8): 6}[(name, quant)])
+    # observed (r03): mha 0.74e-3 / 1.28e-3 (fp16 / int8 KV; noise floor 0.49e-3 / 0.67e-3), gqa 1.34e-3 / 3.27e-3 (0.83e-3 / 2.05e-3)
+    check_steps(res, k={("mha", 0): 1.5, ("mha", 8): 2, ("gqa", 0): 2, ("gqa", 8): 4.5}[(name, quant)])
     if quant == 0:
         # and against the independent HF vectors (fp32 model vs fp16 activations)
         got = np.stack([r[0] for r in res], 1)
@@ -310,8 +326,8 @@ def test_penalty_and_sampling_through_the_abi():
 
 def test_exported_hf_checkpoint_runs_on_the_device(tmp_path_factory):
     """HF checkpoint -> export_hf_llama.py (W8A16) -> pplhip_rank_load on the device == the oracle on the same containers."""
-    pytest.importorskip("transformers")
-    from tests import test_export_hf as te
+    if te is None:
+        pytest.skip("transformers is not importable")
     import json
     m = load_pplhip()
     d, prompt, _ = te.make_hf_checkpoint(tmp_path_factory.mktemp("hf"))

@@ -133,6 +133,8 @@ def check(name, res, k):
         worst = max(worst, err)
         noise = max(noise, float(np.abs(alt - want).max()) / scale)
         assert err <= 1e-3 * k, (name, s, err)
+        n_s = float(np.abs(alt - want).max()) / scale
+        assert n_s == 0 or err <= max(1e-3, 2.5 * n_s), (name, s, err, n_s)   # and within 2.5 x the oracle's own summation-order noise
         srt = np.sort(want, -1)
         safe = (srt[:, -1] - srt[:, -2]) > 2e-3 * k * scale
         assert (gtok[safe] == want.argmax(-1)[safe]).all(), (name, s)
@@ -241,7 +243,7 @@ def test_llama13b_tp2_rank_slices_w8a16():
         g.set_tensors(r, tensors)
     del weights
     prompts = [rng.randint(3, V, size=n) for n in (70, 3, 129, 1, 16)]
-    check("llama13b_tp2_w8a16_int8kv", generate(g, prompts, 3), k=4)   # observed 2.5e-3 (int8 KV, 40 heads, K up to 6912)
+    check("llama13b_tp2_w8a16_int8kv", generate(g, prompts, 3), k=3.5)   # observed 2.4e-3, 1.4 x the oracle's own noise floor of 1.7e-3 (int8 KV, 40 heads, K up to 6912)
     g.close()
 
 
@@ -270,7 +272,7 @@ def test_llama70b_tp8_rank_slices_w4a16_decode_at_kv2048():
         res.append((got, want, gtok, g.last_alt))
         tok = want.argmax(-1).astype(np.int64)
         start = start + 1
-    check("llama70b_tp8_w4a16_decode_kv2048", res, k=6)   # observed 4.1e-3: grouped-query MFMA decode over int8 KV (see test_gpu_model.py)
+    check("llama70b_tp8_w4a16_decode_kv2048", res, k=1.5)   # observed (r03) < 0.8e-3 with the exact hi + lo operands of the grouped-query kernel (r02: 4.1e-3)
     # cache-prefill: 40 and 17 new tokens on top of 512 and 33 cached ones (history from the synthetic slab)
     prompts = [rng.randint(3, 32000, size=40), rng.randint(3, 32000, size=17)]
     check("llama70b_tp8_w4a16_cache_prefill", generate(g, prompts, 2, start=[512, 33]), k=1.5)   # observed 5.4e-4
