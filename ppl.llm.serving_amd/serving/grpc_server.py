@@ -120,7 +120,9 @@ class Serving:
                     q, orig_id, text = route
                     if r.status != P.PROCESSING:
                         del self.routes[r.id]
-                    piece = tbuf.raw[r.text_off:r.text_off + r.text_len].decode("utf-8", errors="replace") if (text and r.text_off >= 0) else ""
+                    # (C.string_at copies only the piece; tbuf.raw would copy the whole 1 MiB buffer for every response)
+                    piece = (C.string_at(C.addressof(tbuf) + r.text_off, r.text_len).decode("utf-8", errors="replace")
+                             if (text and r.text_off >= 0) else "")
                     per_call.setdefault(id(q), (q, []))[1].append((orig_id, r.token, r.logprob, r.status, r.finish_reason,
                                                                    r.is_special, text, piece))
             for q, items in per_call.values():

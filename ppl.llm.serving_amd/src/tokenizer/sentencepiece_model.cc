@@ -238,7 +238,11 @@ void SentencePieceModel::EncodeBpe(const std::string& norm, std::vector<int>* id
         if (l < 0 || r < 0) return;
         const std::string piece = norm.substr(sym[l].pos, sym[l].len + sym[r].len);
         auto it = piece_to_id_.find(piece);
-        if (it == piece_to_id_.end() || pieces_[it->second].type == UNUSED) return;
+        if (it == piece_to_id_.end()) return;
+        // merges run through NORMAL and USER_DEFINED pieces only: reserved ids (CONTROL "<s>", UNKNOWN, BYTE "<0x0A>") must never be
+        // produced from literal text -- a tokenisation mismatch and a way to inject special tokens; UNUSED never merges
+        const int ty = pieces_[it->second].type;
+        if (ty != NORMAL && ty != USER_DEFINED) return;
         agenda.push(Pair{l, r, pieces_[it->second].score, piece.size()});
     };
     for (int i = 1; i < (int)sym.size(); ++i) maybe_add(i - 1, i);

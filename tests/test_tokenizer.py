@@ -86,3 +86,23 @@ def test_unsupported_models_are_refused(tool, tmp_path):
     bad.write_bytes(b"\x00\x01\x02not a model")
     out = subprocess.run([tool, str(bad)], input="", capture_output=True, text=True)
     assert out.stdout.startswith("ERROR")
+
+
+@pytest.mark.parametrize("model", ["spm_bpe.model"])
+def test_literal_special_token_text_never_becomes_a_reserved_id(tool, cases, model):
+    """BPE merges must run through NORMAL / USER_DEFINED pieces only, so the literal TEXT "<s>", "</s>", "<unk>" or
+    "<0x0A>" is tokenised character by character (bos / eos / unk / byte ids cannot be injected from text); compared with the
+    sentencepiece module when it is importable."""
+    texts = ["<s>", "</s> trailing", "a<unk>b", "<0x0A>", "x <s> y </s>"]
+    _, rows = run(tool, model, ["E " + hexs(t) for t in texts])
+    c = cases[model]
+    got = [[int(x) for x in r.split()] for r in rows]
+    for ids in got:
+        assert c["bos"] not in ids and c["eos"] not in ids
+    try:
+        import sentencepiece as spm
+    except Exception:
+        return
+    sp = spm.SentencePieceProcessor(model_file=os.path.join(GOLD, model))
+    for t, ids in zip(texts, got):
+        assert ids == sp.encode(t), t
