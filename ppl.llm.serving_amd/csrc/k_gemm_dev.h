@@ -278,10 +278,16 @@ __device__ __forceinline__ void gemm_dma_body(const uint16_t* __restrict__ x, co
                 const int row = mb + j * 16 + l15;
                 bfr[j] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&xs[row * G_BK + g_swz(row, ks * 4 + kq) * 8]));
             }
+#ifdef GEMM_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], bfr[j], acc[i][j], 0, 0, 0);
+#ifdef GEMM_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
     }
 

@@ -86,6 +86,12 @@ hipError_t launch_p2p_allreduce(hipStream_t s, const P2pPeers& peers, int me, in
 hipError_t launch_p2p_allgather(hipStream_t s, const P2pPeers& peers, int me, int n, size_t src_off, void* dst, int64_t rows,
                                 int64_t row_bytes, int64_t dst_row_bytes, uint32_t epoch, uint64_t timeout_ticks, uint32_t* status);
 
+// stream hand-off through a device-memory epoch (k_comm.hip): signal = one-thread kernel after the producer; wait = one-wave kernel
+// in front of the consumer (bounded spin; optionally raises a second flag when the wait is over)
+hipError_t launch_handoff_signal(hipStream_t s, uint32_t* flag, uint32_t epoch);
+hipError_t launch_handoff_wait(hipStream_t s, const uint32_t* wait_flag, uint32_t wait_epoch, uint32_t* done_flag, uint32_t done_epoch,
+                               uint64_t timeout_ticks, uint32_t* status);
+
 // self-test patterns: halfs[i] = value(i, g, round), floats[i] = value(i, g, round + 2)
 float p2p_pattern_value(int64_t i, int g, int round);
 hipError_t launch_p2p_pattern(hipStream_t s, uint16_t* halfs, int64_t cnt, float* floats, int64_t gcnt, int g, int round);

@@ -118,6 +118,10 @@ struct Rank {
     uint32_t p2p_epoch = 0;
     uint32_t* p2p_status = nullptr;     // pinned host word a kernel raises when one of its bounded spins timed out
     int32_t* d_flag = nullptr;          // one int for the cross-process agreement on the self-test
+    // stream hand-offs of the two-chunk schedule through device-memory epochs (k_comm.hip handoff_*): words 0..1 = "chunk i's
+    // partial sums are complete" (compute -> communication stream), 2..3 = "chunk i is reduced" (communication -> compute)
+    uint32_t* hflags = nullptr;
+    uint32_t h_ready_ep[2] = {0, 0}, h_done_ep[2] = {0, 0};
 
     // diagnosis (pplhip_debug_run_dump): residual stream h and the pending row-parallel FFN output after every layer
     uint16_t* dump_dev = nullptr;  // [L+1][2][T, hidden] fp16 (slot 0 = h, slot 1 = pending), allocated for one run
@@ -140,6 +144,7 @@ struct pplhip_ctx {
     // of 8 MB it hides are worth -- so it is used for steps that carry prefill tokens (T >= 2048: 16+ MB per
     // all-reduce, chunks of >= 1024 rows keep the GEMM tiles full), not for pure decode steps of <= 1024 rows.
     int64_t tp_overlap_min_tokens = 2048;
+    bool handoff_flags = true;  // PPLHIP_TP_HANDOFF=events: HIP events instead of device-memory epochs between the two streams
     bool tp_on = false;     // the tensor-parallel step schedule (collectives after wo / w2, logits gather) is active
     // collectives: 2 = direct kernels over peer-mapped memory (k_comm.hip), 1 = RCCL, 0 = none.  PPLHIP_COMM=auto (default:
     // direct when the self-test passes on every rank, else RCCL) | p2p (direct or fail) | rccl
@@ -428,6 +433,8 @@ int p2p_connect_local(pplhip_ctx* c) {
 // a kernel of the direct path gave up waiting for a peer: surfaced at the step's synchronisation points
 int p2p_check(pplhip_ctx* c, int rank) {
     Rank& R = c->ranks[rank];
+    if (R.p2p_status && *R.p2p_status == 64)
+        return fail(c, rank, PPLHIP_DEVICE_RUNTIME_ERROR, "stream hand-off timed out (compute / communication stream of a tensor-parallel step)");
     if (c->comm_mode == 2 && R.p2p_status && *R.p2p_status) {
         const uint32_t v = *R.p2p_status;
         return fail(c, rank, PPLHIP_DEVICE_RUNTIME_ERROR, "direct collective timed out waiting for rank " + std::to_string((v - 1) & 15) +
@@ -582,6 +589,7 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
         c->comm_want = 1;
     }
     if (const char* e = getenv("PPLHIP_TP_OVERLAP")) c->tp_overlap = atoi(e) != 0;
+    if (const char* e = getenv("PPLHIP_TP_HANDOFF")) c->handoff_flags = strcmp(e, "events") != 0;
     if (const char* e = getenv("PPLHIP_TP_OVERLAP_MIN_TOKENS")) c->tp_overlap_min_tokens = std::max(2, atoi(e));
     if (want_comm && c->comm_want != 2) {
         std::vector<ncclComm_t> comms(n);
@@ -685,6 +693,8 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
             HIPCK(cp, r, hipHostMalloc((void**)&R.p2p_status, 64, hipHostMallocMapped));
             *R.p2p_status = 0;
             ALLOC(R.d_flag, 64);
+            ALLOC(R.hflags, 64);
+            HIPCK(cp, r, hipMemset(R.hflags, 0, 64));
         }
         const int inter_p = (d.weight_quant_bit != 4) ? (c->inter + k_tile(d) - 1) / k_tile(d) * k_tile(d) : c->inter;  // = layers[*].w2.Kp
         if (d.act_quant_bit == 8) {  // online_i8i8: the int8 copy of whatever feeds the next linear + its per-token scales
@@ -1220,6 +1230,19 @@ static int chunk_allreduce(pplhip_ctx* c, int rank, uint16_t* buf, const Chunk& 
     };
     static const int dbg = getenv("PPLHIP_TP_DEBUG") ? atoi(getenv("PPLHIP_TP_DEBUG")) : 0;
     if (!overlapped || (dbg & 2)) return reduce_on(R.stream);
+    if (c->handoff_flags) {
+        // compute stream: "chunk ci's partial sums are complete"; communication stream: wait for that, reduce, "chunk ci is reduced"
+        HIPCK(c, rank, launch_handoff_signal(R.stream, R.hflags + ci, ++R.h_ready_ep[ci]));
+        const bool identity = c->comm_mode != 2 && !R.comm;  // ranks emulated on one device (bench.py --emulate-tp): nothing to reduce
+        HIPCK(c, rank, launch_handoff_wait(R.comm_stream, R.hflags + ci, R.h_ready_ep[ci], identity ? R.hflags + 2 + ci : nullptr,
+                                           identity ? R.h_done_ep[ci] + 1 : 0, c->p2p_timeout_ticks, R.p2p_status));
+        ++R.h_done_ep[ci];
+        if (!identity) {
+            if (int rc = reduce_on(R.comm_stream)) return rc;
+            HIPCK(c, rank, launch_handoff_signal(R.comm_stream, R.hflags + 2 + ci, R.h_done_ep[ci]));
+        }
+        return 0;
+    }
     if (dbg & 1) {  // diagnosis: never re-record an event inside a step
         hipEventCreateWithFlags(&R.ev_compute[ci], hipEventDisableTiming);
         hipEventCreateWithFlags(&R.ev_comm[ci], hipEventDisableTiming);
@@ -1228,6 +1251,16 @@ static int chunk_allreduce(pplhip_ctx* c, int rank, uint16_t* buf, const Chunk& 
     HIPCK(c, rank, hipStreamWaitEvent(R.comm_stream, R.ev_compute[ci], 0));
     if (int rc = reduce_on(R.comm_stream)) return rc;
     HIPCK(c, rank, hipEventRecord(R.ev_comm[ci], R.comm_stream));
+    return 0;
+}
+
+// the compute stream picks up chunk ci's reduced rows
+static int wait_reduced(pplhip_ctx* c, int rank, int ci) {
+    Rank& R = c->ranks[rank];
+    if (c->handoff_flags)
+        HIPCK(c, rank, launch_handoff_wait(R.stream, R.hflags + 2 + ci, R.h_done_ep[ci], nullptr, 0, c->p2p_timeout_ticks, R.p2p_status));
+    else
+        HIPCK(c, rank, hipStreamWaitEvent(R.stream, R.ev_comm[ci], 0));
     return 0;
 }
 
@@ -1274,23 +1307,23 @@ static int run_launches(pplhip_ctx* c, int rank) {
     if (R.dump_dev) HIPCK(c, rank, hipMemcpyAsync(R.dump_dev, R.h, dump_n * 2, hipMemcpyDeviceToDevice, s));
     for (int l = 0; l < d.num_layers; ++l) {
         for (int i = 0; i < nck; ++i) {
-            if (ov && l > 0 && !tpdbg2) HIPCK(c, rank, hipStreamWaitEvent(s, R.ev_comm[i], 0));  // part2 rows of chunk i are reduced
+            if (ov && l > 0 && !tpdbg2 && (rc = wait_reduced(c, rank, i))) return rc;  // part2 rows of chunk i are reduced
             if ((rc = layer_attention_part(c, rank, l, ck[i], pending, split[i], threads))) return rc;
             if (comm && (rc = chunk_allreduce(c, rank, R.part, ck[i], i, ov))) return rc;
         }
         for (int i = 0; i < nck; ++i) {
-            if (ov && !tpdbg2) HIPCK(c, rank, hipStreamWaitEvent(s, R.ev_comm[i], 0));            // part rows of chunk i are reduced
+            if (ov && !tpdbg2 && (rc = wait_reduced(c, rank, i))) return rc;            // part rows of chunk i are reduced
             if ((rc = layer_ffn_part(c, rank, l, ck[i]))) return rc;
             if (comm && (rc = chunk_allreduce(c, rank, R.part2, ck[i], i, ov))) return rc;
         }
         pending = R.part2;
         if (R.dump_dev) {
-            if (ov && !tpdbg2) for (int i = 0; i < nck; ++i) HIPCK(c, rank, hipStreamWaitEvent(s, R.ev_comm[i], 0));
+            if (ov && !tpdbg2) for (int i = 0; i < nck; ++i) if ((rc = wait_reduced(c, rank, i))) return rc;
             HIPCK(c, rank, hipMemcpyAsync(R.dump_dev + (size_t)(l + 1) * 2 * dump_n, R.h, dump_n * 2, hipMemcpyDeviceToDevice, s));
             HIPCK(c, rank, hipMemcpyAsync(R.dump_dev + ((size_t)(l + 1) * 2 + 1) * dump_n, R.part2, dump_n * 2, hipMemcpyDeviceToDevice, s));
         }
     }
-    if (ov && !tpdbg2) for (int i = 0; i < nck; ++i) HIPCK(c, rank, hipStreamWaitEvent(s, R.ev_comm[i], 0));
+    if (ov && !tpdbg2) for (int i = 0; i < nck; ++i) if ((rc = wait_reduced(c, rank, i))) return rc;
     // K11: last-token gather + final (Skip)RMSNorm (the last FFN output is folded into the residual of the gathered
     // rows only) + lm_head (+ all-gather of the vocab shards)
     HIPCK(c, rank, launch_rmsnorm(s, R.h, pending, R.norm, d.norm_eps, B, hd, R.d_seq, R.hn, nullptr));
@@ -1305,8 +1338,13 @@ static int run_launches(pplhip_ctx* c, int rank) {
         // every collective of this communicator is issued on ONE stream (the communication stream when overlapping)
         hipStream_t cs = (ov && !tpdbg2) ? R.comm_stream : s;
         if (ov && !tpdbg2) {
-            HIPCK(c, rank, hipEventRecord(R.ev_compute[0], s));
-            HIPCK(c, rank, hipStreamWaitEvent(cs, R.ev_compute[0], 0));
+            if (c->handoff_flags) {
+                HIPCK(c, rank, launch_handoff_signal(s, R.hflags + 0, ++R.h_ready_ep[0]));
+                HIPCK(c, rank, launch_handoff_wait(cs, R.hflags + 0, R.h_ready_ep[0], nullptr, 0, c->p2p_timeout_ticks, R.p2p_status));
+            } else {
+                HIPCK(c, rank, hipEventRecord(R.ev_compute[0], s));
+                HIPCK(c, rank, hipStreamWaitEvent(cs, R.ev_compute[0], 0));
+            }
         }
         if (c->comm_mode == 2) {  // every rank pulls every shard straight into its [B, V] logits
             HIPCK(c, rank, launch_p2p_allgather(cs, R.peers, R.global_rank, c->tp, R.x_local, R.logits, B, (int64_t)vl * 4,
@@ -1317,8 +1355,13 @@ static int run_launches(pplhip_ctx* c, int rank) {
             return fail(c, rank, PPLHIP_OTHER_ERROR, "tensor-parallel step without collectives");
         }
         if (ov && !tpdbg2) {
-            HIPCK(c, rank, hipEventRecord(R.ev_comm[0], cs));
-            HIPCK(c, rank, hipStreamWaitEvent(s, R.ev_comm[0], 0));
+            if (c->handoff_flags) {
+                HIPCK(c, rank, launch_handoff_signal(cs, R.hflags + 2, ++R.h_done_ep[0]));
+                if ((rc = wait_reduced(c, rank, 0))) return rc;
+            } else {
+                HIPCK(c, rank, hipEventRecord(R.ev_comm[0], cs));
+                HIPCK(c, rank, hipStreamWaitEvent(s, R.ev_comm[0], 0));
+            }
         }
         for (int r = 0; r < c->tp && c->comm_mode != 2; ++r)
             HIPCK(c, rank, hipMemcpy2DAsync(R.logits + (size_t)r * vl, (size_t)d.vocab_size * 4, R.logits_gather + (size_t)r * B * vl,

@@ -91,7 +91,7 @@ def check_steps(res, k, name=None):
     for s, (got, want, gtok, wtok, glp, wlp, alt) in enumerate(res):
         scale = max(1.0, np.abs(want).max())
         noise = np.abs(alt - want).max() / scale
-        rel = min(1e-3 * k, max(1e-3, NOISE_RATIO * noise)) if noise > 0 else 1e-3 * k   # (integer GEMMs have no summation-order noise)
+        rel = min(1e-3 * k, max(1e-3, NOISE_RATIO * noise)) if noise > 1e-5 else 1e-3 * k   # (integer GEMMs have no summation-order noise)
         tol = rel * scale
         err = np.abs(got - want).max()
         record_err(name, err / scale, rel, noise=noise)
