@@ -57,6 +57,13 @@ tp)
   for tp in 2 4 8; do python $R/bench.py --emulate-tp $tp $L 2>/dev/null | python -c "$fmt" "7b_w8a16_b1024_kv512_tp$tp" >> $OUT; done
   python $R/bench.py --model llama2-13b --batch 512 --kv-len 1024 --emulate-tp 2 $L 2>/dev/null | python -c "$fmt" "13b_w8a16_b512_kv1024_tp2(config3)" >> $OUT
   python $R/bench.py --model llama2-70b --weight-quant 4 --batch 256 --kv-len 2048 --emulate-tp 8 $L 2>/dev/null | python -c "$fmt" "70b_w4a16_b256_kv2048_tp8(config4)" >> $OUT
-  python $R/bench.py --cache-mode 1 $L 2>/dev/null | python -c "$fmt" "7b_w8a16_b1024_kv512_tp1_paged16" >> $OUT ;;
+  python $R/bench.py --cache-mode 1 $L 2>/dev/null | python -c "$fmt" "7b_w8a16_b1024_kv512_tp1_paged16" >> $OUT
+  # the same steps WITHOUT event bracketing (--breakdown records ~22 events per layer: at 80 layers x 12 short kernels that is a fifth of the step)
+  L2="--no-cpu-baseline --no-serving-leg --no-i8i8-leg --prefill-sample 0 --ragged-steps 0 --breakdown-steps 0"
+  fmt2='import sys,json; r=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith("{")][-1]); print(sys.argv[1], "ms_per_step", r["ms_per_step"], "attn", r["breakdown_ms_per_step"]["attn_decode"], r["roofline"]["achieved"], "GB/s")'
+  echo "# without --breakdown (only the decode-attention launches carry their dispatch-packet timestamps):" >> $OUT
+  for tp in 2 4 8; do python $R/bench.py --emulate-tp $tp $L2 2>/dev/null | python -c "$fmt2" "7b_w8a16_b1024_kv512_tp$tp" >> $OUT; done
+  python $R/bench.py --model llama2-13b --batch 512 --kv-len 1024 --emulate-tp 2 $L2 2>/dev/null | python -c "$fmt2" "13b_w8a16_b512_kv1024_tp2(config3)" >> $OUT
+  python $R/bench.py --model llama2-70b --weight-quant 4 --batch 256 --kv-len 2048 --emulate-tp 8 $L2 2>/dev/null | python -c "$fmt2" "70b_w4a16_b256_kv2048_tp8(config4)" >> $OUT ;;
 esac; done
 ls -la $R/gpurun_out | tail -25

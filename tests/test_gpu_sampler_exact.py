@@ -142,3 +142,36 @@ def test_full_vocabulary_sampling_top_p_one():
             same += 1
     assert same >= B - 2
     ctx.close()
+
+
+@pytest.mark.parametrize("top_k,n_ties,above", [(50, 300, 19), (8, 5000, 0), (1024, 40, 1000), (0, 2000, 500)])
+def test_equal_values_straddling_the_candidate_cut_are_taken_in_index_order(top_k, n_ties, above):
+    """`above` logits lie over a plateau of `n_ties` EQUAL logits that the candidate cut (top_k, or 1024 in pure top-p mode) falls
+    into: the candidates are the plateau's LOWEST indices (DESIGN.md "sampler": ties -> lower index first) -- the index-selection
+    passes of the radix select, which random logits never reach.  With top_p = 1 the plateau holds most of the candidate mass,
+    so most picks land on plateau members; tokens must equal the oracle's."""
+    m = load_pplhip()
+    rng = np.random.RandomState(top_k + n_ties)
+    B, V = 16, 32000
+    logits = (rng.randn(B, V) * 0.5 - 6.0).astype(np.float32)
+    for b in range(B):
+        idx = rng.permutation(V)
+        logits[b, idx[:above]] = (2.0 + rng.rand(above)).astype(np.float32)          # clearly above the plateau
+        logits[b, idx[above:above + n_ties]] = np.float32(1.25)                      # the plateau
+    ctx = make_ctx(m, V, B)
+    d = torch.from_numpy(logits).cuda()
+    seq = replay(11, 3, B)
+    for s in range(3):
+        tok, _ = ctx.sample(B, top_k=top_k, top_p=1.0, logits_ptr=d.data_ptr())
+        wtok, _ = ref.sample(logits, top_k=top_k, top_p=1.0, rnd=seq[s])
+        k = 1024 if top_k <= 0 else min(top_k, 1024)
+        for b in range(B):
+            _, margin = decision_margins(logits[b], top_k, 1.0, seq[s][b])
+            if margin < 3e-6:
+                continue
+            assert tok[b] == wtok[b], (s, b, int(tok[b]), int(wtok[b]))
+            # and a plateau pick is one of the plateau's k - above lowest indices
+            if logits[b, tok[b]] == np.float32(1.25) and k > above:
+                plateau = np.flatnonzero(logits[b] == np.float32(1.25))
+                assert tok[b] in plateau[:k - above]
+    ctx.close()
