@@ -135,7 +135,7 @@ __global__ __launch_bounds__(GQ_THREADS) void attn_decode_gqa_kernel(const uint1
             int64_t slot_b;
             if (MODE == 0) slot_b = slot0 + kbc;
             else {
-                const int64_t pg = kbc / kv.page_size;
+                const int64_t pg = kv.page_shift >= 0 ? (kbc >> kv.page_shift) : kbc / kv.page_size;
                 slot_b = cache_indices[b * max_pages + pg] * kv.page_size + (kbc - pg * kv.page_size);
             }
             const char* kp = kbase + slot_b * rowb;

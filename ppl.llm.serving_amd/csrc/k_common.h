@@ -108,6 +108,7 @@ struct KvAddr {
     int64_t sKV, sH, sN;       // element strides in the cache
     int64_t ssKV, ssH, ssN;    // element strides in the scale slab
     int32_t mode, page_size;   // cache_mode (0 contiguous / 1 paged)
+    int32_t page_shift;        // log2(page_size) when it is a power of two (the usual 16), else -1: a 64-bit division per KV row is ~50 VALU ops
 };
 
 // KV slot of (request b, position pos): mode 0 cache_indices[b] + pos; mode 1 paged
@@ -115,6 +116,10 @@ struct KvAddr {
 __device__ __forceinline__ int64_t kv_slot(const KvAddr& a, const int64_t* __restrict__ cache_indices, int64_t max_pages,
                                            int64_t b, int64_t pos) {
     if (a.mode == 0) return cache_indices[b] + pos;
+    if (a.page_shift >= 0) {
+        const int64_t pg = pos >> a.page_shift;
+        return (cache_indices[b * max_pages + pg] << a.page_shift) + (pos & (int64_t)(a.page_size - 1));
+    }
     const int64_t pg = pos / a.page_size;
     return cache_indices[b * max_pages + pg] * a.page_size + (pos - pg * a.page_size);
 }

@@ -248,6 +248,7 @@ KvAddr make_kv_addr(const pplhip_model_desc& d, int Hkv, int D, uint64_t tokens,
     a.ssKV = ss.sKV; a.ssH = ss.sH; a.ssN = ss.sN;
     a.mode = d.cache_mode;
     a.page_size = d.page_size > 0 ? d.page_size : 1;
+    a.page_shift = (a.page_size & (a.page_size - 1)) == 0 ? __builtin_ctz((unsigned)a.page_size) : -1;
     return a;
 }
 
