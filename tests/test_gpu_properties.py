@@ -1,6 +1,8 @@
 """Size-independent properties at the FULL model size of the benchmark configuration (LLaMA-2-7B dimensions, 32 layers,
-W8A16, int8-g8 KV) -- sizes at which the CPU oracle would take minutes per step, so parity is checked through
-invariants that must hold exactly (bit-for-bit) or to rounding:
+W8A16, int8-g8 KV): invariants that must hold exactly (bit-for-bit) or to rounding, whatever the oracle says.  (The direct
+comparison of this model with the oracle -- logits and the residual stream after every layer, against the oracle's own noise
+floor -- is tests/test_gpu_fulldepth.py; the two "to rounding" properties below are two more samples of that noise floor:
+1.2-1.6e-2 between two correct fp16 implementations at this depth.)
   * cache-layout / cache-mode invariance: the four KV layouts and contiguous vs paged slots change addressing only;
   * batch-permutation equivariance: permuting the requests of a step permutes the logits rows, bit for bit;
   * prefill / decode consistency: logits after prefilling n+1 tokens == prefilling n tokens then decoding 1;
@@ -105,7 +107,7 @@ def test_permutation_determinism_and_prefill_decode_consistency(prompts):
     step = a1[2]
     scale = max(1.0, np.abs(full).max())
     # two different kernel paths over 32 layers with int8 KV (MFMA prefill attention + tile GEMM vs the VALU decode kernel +
-    # skinny GEMM): observed (r02) 7.0e-3
+    # skinny GEMM): observed 7.0e-3 -- half the oracle's own summation-order noise at this depth (tests/test_gpu_fulldepth.py)
     record_err("7b_prefill_vs_decode_consistency", np.abs(full - step).max() / scale, 1e-2)
     assert np.abs(full - step).max() <= 1e-2 * scale
     srt = np.sort(full)
