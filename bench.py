@@ -513,6 +513,15 @@ def main():
             "breakdown_ms_per_step": {"attn_decode": round(ms_attn / K, 3), "gemm": round(gemm_ms_per_step, 3) if gemm_ms_per_step is not None else None,
                                       "run_total_gpu": round(ms_run / K, 3), "note": gemm_note},
         }
+        if gemm_ms_per_step:
+            # the second kernel class of the step: W8A16 / W4A16 tile GEMMs (4 per layer + lm_head), MFMA-bound at this batch
+            hd_, it_ = desc.hidden_dim, desc.intermediate_dim // tp
+            per_layer = (H + 2 * Hkv) * D * hd_ + hd_ * H * D + 2 * it_ * hd_ + hd_ * it_
+            flops = 2.0 * B * (desc.num_layers * per_layer + (desc.vocab_size // tp) * hd_)
+            tf = flops / (gemm_ms_per_step * 1e-3) / 1e12
+            res["roofline_gemm"] = {"kernel": "gemm_dma_kernel (128x128x64 LDS-DMA tiles)", "bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0,
+                                    "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "flops_per_step": flops,
+                                    "note": "dense fp16 MFMA peak; durations from the bracketed extra steps (breakdown_ms_per_step.gemm)"}
         res.update(extra)
         if ragged is not None:
             res["ragged_batch"] = ragged
