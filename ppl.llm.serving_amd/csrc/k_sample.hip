@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void sample_topk_topp_kernel(const float* __re
                                                                int32_t* __restrict__ out_tok, float* __restrict__ out_lp) {
     __shared__ float sf[4];
     __shared__ int wsum[4], sel[4], hist[256];
-    __shared__ float cv[TOPK_MAX];   // candidate values, later their masses exp(x - max)
+    __shared__ float cv[TOPK_MAX];   // candidate values x = logit / temperature
     __shared__ float cum[TOPK_MAX];  // inclusive cumulative mass of the sorted candidates
     __shared__ int ci[TOPK_MAX];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -215,9 +215,8 @@ __global__ __launch_bounds__(256) void sample_topk_topp_kernel(const float* __re
             }
             __syncthreads();
         }
-    // masses and their inclusive scan (Hillis-Steele over <= 1024 entries, ping-pong between cum and cv is not needed: each
-    // thread owns entries tid, tid + 256, ... and reads strictly lower ones written in the previous round)
-    const float vsel_dummy = 0.f; (void)vsel_dummy;
+    // masses exp(x - max) of the sorted candidates and their inclusive scan (Hillis-Steele over <= 1024 entries; every round reads
+    // all its operands into registers, then a barrier, then adds: no second buffer needed)
     float xv[TOPK_MAX / 256];
 #pragma unroll
     for (int j = 0; j < TOPK_MAX / 256; ++j) {
@@ -228,7 +227,7 @@ __global__ __launch_bounds__(256) void sample_topk_topp_kernel(const float* __re
 #pragma unroll
     for (int j = 0; j < TOPK_MAX / 256; ++j) {
         const int i = tid + j * 256;
-        if (i < n2) { const float e = i < k ? expf(xv[j] - mx) : 0.f; cv[i] = e; cum[i] = e; }
+        if (i < n2) cum[i] = i < k ? expf(xv[j] - mx) : 0.f;
     }
     __syncthreads();
     for (int o = 1; o < n2; o <<= 1) {
