@@ -294,18 +294,23 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
             // elements (twice the oracle's own summation-order noise on the HF fixtures, tests/test_gpu_model.py)
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) {
+                // hi = p truncated to 11 significant bits (a mask: exactly an fp16 number for p >= 2^-14), lo = p - hi (exact in fp32);
+                // both packed to fp16 by v_cvt_pkrtz (hi converts exactly, lo keeps 11 more bits): 3 VALU ops per probability
                 h8 pa[RG], pl[RG];
 #pragma unroll
-                for (int g = 0; g < RG; ++g)
+                for (int g = 0; g < RG; ++g) {
+                    typedef __fp16 pk_h2 __attribute__((ext_vector_type(2)));
+                    uint32_t hw[4], lw[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float p0 = sacc[g][2 * s2][r], p1 = sacc[g][2 * s2 + 1][r];
-                        const _Float16 h0 = to_h(p0), h1 = to_h(p1);
-                        pa[g][r] = h0;
-                        pa[g][4 + r] = h1;
-                        pl[g][r] = to_h(p0 - (float)h0);
-                        pl[g][4 + r] = to_h(p1 - (float)h1);
+                    for (int q2 = 0; q2 < 4; ++q2) {  // pairs (r, r+1) of tile 2*s2 (q2 = 0, 1) and of tile 2*s2 + 1 (q2 = 2, 3)
+                        const float p0 = sacc[g][2 * s2 + (q2 >> 1)][(q2 & 1) * 2], p1 = sacc[g][2 * s2 + (q2 >> 1)][(q2 & 1) * 2 + 1];
+                        const float h0 = __uint_as_float(__float_as_uint(p0) & 0xffffe000u), h1 = __uint_as_float(__float_as_uint(p1) & 0xffffe000u);
+                        hw[q2] = __builtin_bit_cast(uint32_t, (pk_h2)__builtin_amdgcn_cvt_pkrtz(h0, h1));
+                        lw[q2] = __builtin_bit_cast(uint32_t, (pk_h2)__builtin_amdgcn_cvt_pkrtz(p0 - h0, p1 - h1));
                     }
+                    pa[g] = __builtin_bit_cast(h8, make_uint4(hw[0], hw[1], hw[2], hw[3]));
+                    pl[g] = __builtin_bit_cast(h8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
+                }
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
                     const uint2 lo = v_frag_tr(Vs, (2 * s2) * DT + dt, kq, l15);      // keys 16*(2s) + kq*4 .. +4 of channel dt*16 + l15
