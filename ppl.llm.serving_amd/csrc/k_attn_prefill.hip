@@ -22,10 +22,13 @@
 
 namespace pplhip {
 
-constexpr int PF_BM = 128;  // query rows per block
+#ifndef PF_NW
+#define PF_NW 8   // waves per block, 16 query rows each (4, two blocks per CU: equal at 8192 tokens, 12-18 % slower on shorter prompts -- every staged tile serves half the rows)
+#endif
+constexpr int PF_BM = 16 * PF_NW;  // query rows per block
 constexpr int PF_BN = 128;  // keys per tile
 constexpr int PF_VSUB = 272;  // halfs per [16 keys][16 channels] V sub-tile in LDS: 256 + 16 of skew (bank spread of the writes)
-constexpr int PF_THREADS = 512;
+constexpr int PF_THREADS = 64 * PF_NW;
 
 template <int D>
 __device__ __forceinline__ int k_swz(int key) {
