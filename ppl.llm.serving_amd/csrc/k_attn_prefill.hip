@@ -26,6 +26,9 @@ namespace pplhip {
 #define PF_NW 8   // waves per block, 16 query rows each (4, two blocks per CU: equal at 8192 tokens, 12-18 % slower on shorter prompts -- every staged tile serves half the rows)
 #endif
 constexpr int PF_BM = 16 * PF_NW;  // query rows per block
+#ifndef PF_ABLATE
+#define PF_ABLATE 0   // diagnosis builds only (wrong results): 1 no exp, 2 no staging inside the loop, 4 no barriers, 8 no lo MFMA
+#endif
 constexpr int PF_BN = 128;  // keys per tile
 constexpr int PF_VSUB = 272;  // halfs per [16 keys][16 channels] V sub-tile in LDS: 256 + 16 of skew (bank spread of the writes)
 constexpr int PF_THREADS = 64 * PF_NW;
@@ -128,23 +131,49 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
     // ---- register staging of one tile: raw 16-byte pieces of two adjacent keys (+ their int8 group scales) ---------
     uint4 kraw[IPT][2], vraw[IPT][2];
     uint32_t ksc[IPT][2], vsc[IPT][2];  // int8: two fp16 scales (the piece's two groups of 8 channels)
+    // Addressing (round 3: the address arithmetic of this lambda was 235 of a tile's ~620 VALU instructions per wave, in a VALU-bound
+    // kernel): with contiguous slots the rows of a tile are consecutive slots, so the row base is ONE scalar 64-bit computation
+    // per tile and a lane adds a 32-bit offset (key-in-tile x row pitch + piece); with pages, the two keys of an item share a page
+    // whenever the page size is even (one table lookup per pair; shift addressing for power-of-two pages).
+    const int64_t rowb = kv.sN * ELT, srow = kv.ssN;   // row pitch of the cache (bytes) and of the scales (halfs)
+    const int rowb32 = (int)rowb, srow32 = (int)srow;  // a tile spans 128 rows: the lane part fits 32 bits
+    const bool pair_in_page = MODE == 1 && (kv.page_size % 2 == 0);
     auto load_tile = [&](int tile) {
         const int64_t key0 = (int64_t)tile * PF_BN;
+        const int last = (int)(kv_end - 1 - key0);  // >= 0: keys past kv_end re-read the last valid row (masked later: beyond every row's causal horizon)
 #pragma unroll
         for (int it = 0; it < IPT; ++it) {
             const int item = threadIdx.x + it * PF_THREADS;
             if (NITEMS % PF_THREADS == 0 || item < NITEMS) {  // compile-time true for D = 128: no exec branch around the loads
                 const int c = item % LPT, kp = item / LPT;
+                if constexpr (MODE == 0) {
+                    const char* kt = kbase + (slot0 + key0) * rowb;  // tile-uniform
+                    const char* vt = vbase + (slot0 + key0) * rowb;
+                    const uint16_t* kst = ksbase + (slot0 + key0) * srow;
+                    const uint16_t* vst = vsbase + (slot0 + key0) * srow;
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    int64_t key = key0 + 2 * kp + e;
-                    if (key >= kv_end) key = kv_end - 1;  // masked later (beyond every row's causal horizon)
-                    const int64_t slot = MODE == 0 ? slot0 + key : kv_slot(kv, cache_indices, max_pages, b, key);
-                    kraw[it][e] = *reinterpret_cast<const uint4*>(kbase + (slot * kv.sN + c * CH) * ELT);
-                    vraw[it][e] = *reinterpret_cast<const uint4*>(vbase + (slot * kv.sN + c * CH) * ELT);
-                    if constexpr (QBIT == 8) {
-                        ksc[it][e] = *reinterpret_cast<const uint32_t*>(ksbase + slot * kv.ssN + c * 2);
-                        vsc[it][e] = *reinterpret_cast<const uint32_t*>(vsbase + slot * kv.ssN + c * 2);
+                    for (int e = 0; e < 2; ++e) {
+                        const int kk = (2 * kp + e) < last ? (2 * kp + e) : last;
+                        kraw[it][e] = *reinterpret_cast<const uint4*>(kt + (kk * rowb32 + c * 16));
+                        vraw[it][e] = *reinterpret_cast<const uint4*>(vt + (kk * rowb32 + c * 16));
+                        if constexpr (QBIT == 8) {
+                            ksc[it][e] = *reinterpret_cast<const uint32_t*>(kst + (kk * srow32 + c * 2));
+                            vsc[it][e] = *reinterpret_cast<const uint32_t*>(vst + (kk * srow32 + c * 2));
+                        }
+                    }
+                } else {
+                    const int k0i = (2 * kp) < last ? (2 * kp) : last, k1i = (2 * kp + 1) < last ? (2 * kp + 1) : last;
+                    const int64_t s0 = kv_slot(kv, cache_indices, max_pages, b, key0 + k0i);
+                    const int64_t s1 = pair_in_page ? s0 + (k1i - k0i) : kv_slot(kv, cache_indices, max_pages, b, key0 + k1i);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int64_t slot = e ? s1 : s0;
+                        kraw[it][e] = *reinterpret_cast<const uint4*>(kbase + slot * rowb + c * 16);
+                        vraw[it][e] = *reinterpret_cast<const uint4*>(vbase + slot * rowb + c * 16);
+                        if constexpr (QBIT == 8) {
+                            ksc[it][e] = *reinterpret_cast<const uint32_t*>(ksbase + slot * srow + c * 2);
+                            vsc[it][e] = *reinterpret_cast<const uint32_t*>(vsbase + slot * srow + c * 2);
+                        }
                     }
                 }
             }
@@ -199,9 +228,9 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
     load_tile(0);
     for (int tile = 0; tile < ntiles; ++tile) {
         const int64_t key0 = (int64_t)tile * PF_BN;
-        store_tile();
-        __syncthreads();
-        if (tile + 1 < ntiles) load_tile(tile + 1);  // in flight during the MFMAs below
+        if (!(PF_ABLATE & 2) || tile == 0) store_tile();
+        if (!(PF_ABLATE & 4)) __syncthreads();
+        if (tile + 1 < ntiles && !(PF_ABLATE & 2)) load_tile(tile + 1);  // in flight during the MFMAs below
 
         // a wave whose rows all end before this tile starts has nothing to add (causal); inside an active wave a row group
         // that lies before the tile is merely masked (alpha = 1, all probabilities 0)
@@ -272,7 +301,7 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
                 for (int j = 0; j < 8; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float e = __builtin_amdgcn_exp2f(sacc[g][j][r] - mnew);  // masked scores: 2^(-1e30 - m) = 0
+                        const float e = (PF_ABLATE & 1) ? (sacc[g][j][r] - mnew) * 1e-3f : __builtin_amdgcn_exp2f(sacc[g][j][r] - mnew);  // masked scores: 2^(-1e30 - m) = 0
                         sacc[g][j][r] = e;
                         rs += e;
                     }
@@ -321,13 +350,13 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
                     const h8 bv = __builtin_bit_cast(h8, make_uint4(lo.x, lo.y, hi.x, hi.y));
 #pragma unroll
                     for (int g = 0; g < RG; ++g) {
-                        o[g][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl[g], bv, o[g][dt], 0, 0, 0);
+                        if (!(PF_ABLATE & 8)) o[g][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl[g], bv, o[g][dt], 0, 0, 0);
                         o[g][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa[g], bv, o[g][dt], 0, 0, 0);
                     }
                 }
             }
         }
-        __syncthreads();
+        if (!(PF_ABLATE & 4)) __syncthreads();
     }
     // ---- epilogue: O / l, fp16, rows kq*4 + r of every group of this wave ------------------------------------------
 #pragma unroll
