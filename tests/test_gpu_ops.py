@@ -309,19 +309,23 @@ LONG_CASES = [  # (new tokens, cached tokens) per request, (H, Hkv)
     ([1024], [0], (2, 2)), ([2048, 5], [0, 0], (2, 2)), ([4096], [0], (8, 1)), ([1500, 700], [300, 4000], (2, 2)),
     # BASELINE config 5: 2048 new tokens behind a 6144-token cached prefix (benchmark_prefix_cache_offline shape)
     ([2048], [6144], (2, 2)), ([2048], [6144], (8, 1)),
+    # the 32-row kernel's XCD-aware 1-D grid (k_attn_prefill32.hip): several ragged requests x several query blocks x H = 16 and 24 heads
+    # (2 and 3 heads per XCD), 8-wave blocks (>= 1024 new tokens) and 4-wave blocks, contiguous slots (mode 0) as well as pages
+    ([1100, 37, 1300, 256], [0, 500, 64, 0], (16, 4), 0), ([1100, 37, 1300, 256], [0, 500, 64, 0], (16, 4), 1),
+    ([300, 900, 1], [0, 130, 700], (24, 8), 0),
 ]
 
 
 @pytest.mark.parametrize("quant", [8, 0])
-@pytest.mark.parametrize("seqlens,start,heads", LONG_CASES)
-def test_attention_long_prefill_and_cache_prefill(quant, seqlens, start, heads):
+@pytest.mark.parametrize("seqlens,start,heads,mode", [c if len(c) == 4 else c + (1,) for c in LONG_CASES])
+def test_attention_long_prefill_and_cache_prefill(quant, seqlens, start, heads, mode):
     """prefill / cache-prefill attention against the oracle at 1k .. 8k keys (dozens of 128-key tiles per query tile):
     causal wave skipping, the mask-only-on-diagonal-tiles rule, the conditional rescale across many tiles and the
     8192-key cache-prefill of the prefix-cache benchmark -- paged (16-token pages, shuffled), int8 and fp16 KV."""
     m = load_pplhip()
     H, Hkv = heads
     D = 128
-    case = KvCase(m, H, Hkv, D, L=1, layer=0, quant=quant, layout=3, mode=1, seqlens=seqlens, start_pos=start,
+    case = KvCase(m, H, Hkv, D, L=1, layer=0, quant=quant, layout=3, mode=mode, seqlens=seqlens, start_pos=start,
                   seed=len(seqlens) + quant + H, page_size=16, decoding_batches=0)
     rng = np.random.RandomState(17)
     if quant:
