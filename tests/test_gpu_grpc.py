@@ -190,3 +190,29 @@ def test_text_requests_stream_what_the_reference_rule_gives(text_server, golden_
     for i in range(len(prompts)):
         assert len(tokens[i]) == n_new and len(pieces[i]) == n_new
         assert pieces[i] == reference_stream(sp, tokens[i]), (i, pieces[i], tokens[i])
+
+
+def test_text_mode_load_generator(text_server, golden_dir, tmp_path):
+    """serving/client_qps_measure.py = the reference's tools/client_qps_measure.cc: conversation-format dataset, prompts sent as text,
+    max_new_tokens = the recorded answer's token count, ignore_eos_token -> every request generates exactly that many tokens."""
+    spm = pytest.importorskip("sentencepiece")
+    sp = spm.SentencePieceProcessor(model_file=os.path.join(golden_dir, "spm_bpe.model"))
+    convs = [("Hello, my name is", "I am a small model and this is what I say."), ("The president of the United States is", "someone"),
+             ("naïve café 数学 🙂", "yes " * 9), ("What is 2 + 2?", "It is four, as far as anyone can tell."), ("a", "b c d e f g h")]
+    data = [{"id": f"c{i}", "conversations": [{"from": "human", "value": p}, {"from": "gpt", "value": a}]} for i, (p, a) in enumerate(convs)]
+    ds, dump = str(tmp_path / "samples.json"), str(tmp_path / "answers.json")
+    json.dump(data, open(ds, "w"))
+    proc = subprocess.run([sys.executable, os.path.join(PKG, "serving", "client_qps_measure.py"), "--target", text_server, "--tokenizer",
+                           os.path.join(golden_dir, "spm_bpe.model"), "--dataset", ds, "--request_rate", "50", "--dump-answers", dump],
+                          timeout=300, capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    res = json.loads(proc.stdout.strip().splitlines()[-1])
+    want_in = sum(len(sp.encode(p)) for p, _ in convs)
+    want_out = sum(len(sp.encode(a)) for _, a in convs)
+    assert res["failed"] == 0 and res["request_count"] == 5
+    assert res["total_input_len"] == want_in and res["expected_total_gen_len"] == want_out
+    assert res["real_total_gen_len"] == want_out                       # ignore_eos_token: exactly max_new_tokens responses each
+    assert res["tokens_out_per_sec"] > 0 and res["prefill_latency_ms"]["50%"] > 0 and res["avg_latency_decoding_ms"] > 0
+    assert "[RESULT] tokens out per sec:" in proc.stderr and "[RESULT] prefill latency distribution (ms):" in proc.stderr
+    answers = json.load(open(dump))
+    assert sorted(answers) == ["0", "1", "2", "3", "4"] and all(isinstance(t, str) for t in answers.values())
