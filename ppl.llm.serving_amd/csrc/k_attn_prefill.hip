@@ -60,7 +60,7 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
                                                                   const int64_t* __restrict__ start_pos,
                                                                   const int64_t* __restrict__ cache_indices,
                                                                   int64_t max_pages, int64_t b0, int H, int Hkv,
-                                                                  uint16_t* __restrict__ out) {
+                                                                  int nreq, int nqb, uint16_t* __restrict__ out) {
     constexpr int ELT = QBIT == 8 ? 1 : 2;
     constexpr int CH = 16 / ELT;           // channels in one 16-byte piece
     constexpr int LPT = D / CH;            // pieces per row
@@ -73,14 +73,28 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(const uint16_t
     // RG = 2: the Q fragments live in LDS (64 KiB, same chunk swizzle as K) instead of 32 more VGPRs per lane
     __shared__ __attribute__((aligned(16))) uint16_t Qs[RG > 1 ? PF_BM * RG * D : 8];
 
-    const int64_t b = b0 + blockIdx.y;
-    const int hq = blockIdx.z;
+    // 1-D grid in the XCD-aware order of k_attn_prefill32.hip: XCD id % 8 walks H / 8 consecutive heads one after the other, each head's
+    // query tiles heaviest (last) first, so one head's K / V stays in that XCD's L2 and the launch ends with light blocks
+    int hq, qb, r;
+    {
+        const int L = blockIdx.x, per = nqb * nreq;
+        int rem;
+        if ((H & 7) == 0) {
+            const int j = L >> 3;
+            hq = (L & 7) * (H >> 3) + j / per;
+            rem = j % per;
+        } else {
+            hq = L / per;
+            rem = L % per;
+        }
+        qb = rem / nreq;
+        r = rem % nreq;
+    }
+    const int64_t b = b0 + r;
     const int hk = hq / (H / Hkv);
     const int64_t seqlen = seq_starts[b + 1] - seq_starts[b];
     constexpr int BM = PF_BM * RG;
-    // causal work grows with the query tile index: the heaviest tiles are dispatched first (blockIdx.x = 0 is the LAST tile),
-    // so the launch ends with light blocks instead of a few CUs finishing 64-tile blocks alone
-    const int64_t q0 = (int64_t)(gridDim.x - 1 - blockIdx.x) * BM;
+    const int64_t q0 = (int64_t)(nqb - 1 - qb) * BM;
     if (q0 >= seqlen) return;
     const int64_t sp = start_pos[b];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -391,10 +405,11 @@ hipError_t launch_attn_prefill(hipStream_t s, const uint16_t* qkv, const KvAddr&
     static const int forced_rg = getenv("PPLHIP_PREFILL_RG") ? atoi(getenv("PPLHIP_PREFILL_RG")) : 0;
     const int rg = forced_rg == 2 ? 2 : 1;
     const int bm = PF_BM * rg;
-    dim3 grid((unsigned)((max_seq_len + bm - 1) / bm), (unsigned)(B - b0), (unsigned)H);
+    const int nqb = (int)((max_seq_len + bm - 1) / bm), nreq = (int)(B - b0);
+    dim3 grid((unsigned)((int64_t)nqb * nreq * H));
 #define PF_LAUNCH(QB, DD, MD, RGV)                                                                                     \
     hipLaunchKernelGGL((attn_prefill_kernel<QB, DD, MD, RGV>), grid, dim3(PF_THREADS), 0, s, qkv, kv, seq_starts, start_pos, \
-                       cache_indices, max_pages, b0, H, Hkv, out)
+                       cache_indices, max_pages, b0, H, Hkv, nreq, nqb, out)
 #define PF_CASE(QB, DD)                                                                                          \
     if (quant_bit == QB && D == DD) {                                                                            \
         if (kv.mode == 0) { if (rg == 2) PF_LAUNCH(QB, DD, 0, 2); else PF_LAUNCH(QB, DD, 0, 1); }                \
