@@ -207,15 +207,20 @@ constexpr int H_BN = 256, H_BM = 256, H_ST = 3;
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_w8_dma256_kernel(const uint16_t* __restrict__ x, const int8_t* __restrict__ w,
                                                              const uint16_t* __restrict__ scale, int64_t M, int N, int K,
-                                                             void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles) {
+                                                             void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles, int gn, int gm) {
     extern __shared__ __attribute__((aligned(16))) char smem256[];  // H_ST x (X 32 KiB + W 16 KiB)
     uint16_t* const Xs0 = reinterpret_cast<uint16_t*>(smem256);
     int8_t* const Wq0 = reinterpret_cast<int8_t*>(smem256 + H_ST * H_BM * G_BK * 2);
 
+    // block -> tile: XCD x = id % 8 owns the weight tiles n == x (mod 8) and walks them in super-tiles of gn (n) x gm (m) tiles, m
+    // fastest inside a super-tile, super-tiles m-major: the ~32 blocks an XCD runs at a time then touch gn weight tiles and gm
+    // activation tiles per K step instead of 1 and 32 (gn = 1, gm = m_tiles: the old order), i.e. a third of the bytes through its L2
     const int id = blockIdx.x;
     const int xcd = id & 7, slot = id >> 3;
-    const int nt = xcd + 8 * (slot / m_tiles);
-    const int mt = slot % m_tiles;
+    const int per_super = gn * gm, sm_count = m_tiles / gm;
+    const int sup = slot / per_super, within = slot % per_super;
+    const int nt = xcd + 8 * ((sup / sm_count) * gn + within / gm);
+    const int mt = (sup % sm_count) * gm + within % gm;
     if (nt >= n_tiles) return;
     const int n0 = nt * H_BN;
     const int64_t m0 = (int64_t)mt * H_BM;
@@ -476,7 +481,19 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
     if (wq_bit == 8 && K % G_BK == 0 && M >= min_m256 && N >= 1024 && !force_generic) {
         const int nt2 = (N + H_BN - 1) / H_BN, mt2 = (int)((M + H_BM - 1) / H_BM);
         const size_t lds = (size_t)H_ST * (H_BM * G_BK * 2 + H_BN * G_BK);
-        dim3 g256((unsigned)((nt2 + 7) / 8 * 8 * mt2));
+        // super-tile shape: gm = the largest divisor of mt2 <= 4 (X tiles carry twice the bytes of W tiles), gn = up to 8 weight tiles
+        // of the XCD's share; the share is padded to whole super-tiles (the extra blocks return at once)
+        static const int forced_gm = getenv("PPLHIP_GEMM256_GM") ? atoi(getenv("PPLHIP_GEMM256_GM")) : 0;
+        static const int forced_gn = getenv("PPLHIP_GEMM256_GN") ? atoi(getenv("PPLHIP_GEMM256_GN")) : 0;
+        const int nl = (nt2 + 7) / 8;  // weight tiles per XCD
+        int gm = 4;
+        if (forced_gm > 0) gm = forced_gm;
+        while (gm > 1 && mt2 % gm) --gm;
+        if (mt2 % gm) gm = 1;
+        int gn = forced_gn > 0 ? forced_gn : 8;
+        if (gn > nl) gn = nl;
+        const int nl_pad = (nl + gn - 1) / gn * gn;
+        dim3 g256((unsigned)(8 * nl_pad * mt2));
         // (the attribute belongs to the function ON THE CURRENT DEVICE: one flag per device, or the other ranks of a single-process
         // tensor-parallel run would launch without it)
         static bool attr_dev[64] = {false};
@@ -489,7 +506,7 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
             (void)hipFuncSetAttribute((const void*)gemm_w8_dma256_kernel<EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }
-#define L256(E) hipLaunchKernelGGL((gemm_w8_dma256_kernel<E>), g256, dim3(512), lds, s, x, (const int8_t*)w, scale, M, N, K, y, ldy, nt2, mt2)
+#define L256(E) hipLaunchKernelGGL((gemm_w8_dma256_kernel<E>), g256, dim3(512), lds, s, x, (const int8_t*)w, scale, M, N, K, y, ldy, nt2, mt2, gn, gm)
         if (epi == EPI_F32) L256(EPI_F32); else if (epi == EPI_F16) L256(EPI_F16); else L256(EPI_SWIGLU);
 #undef L256
         return hipGetLastError();
@@ -503,6 +520,21 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         // (mode 1) by 2-4 % on every layer shape
         int map_mode = (forced == 1 && m_tiles % 8 == 0) ? 1 : 0;
         dim3 g2 = map_mode == 1 ? dim3((unsigned)(n_tiles * m_tiles)) : grid;
+        if (map_mode == 0 && m_tiles > 8) {
+            // more than 8 activation tiles (M > 1024): walk the XCD's weight tiles in super-tiles of 12 (n) x 8 (m) -- at M = 1024 the
+            // plain order already is that shape; at M = 8192 it degenerates to 1.5 weight tiles x 64 activation tiles in flight per XCD
+            static const int forced_gm = getenv("PPLHIP_GEMM128_GM") ? atoi(getenv("PPLHIP_GEMM128_GM")) : 0;
+            static const int forced_gn = getenv("PPLHIP_GEMM128_GN") ? atoi(getenv("PPLHIP_GEMM128_GN")) : 0;
+            int gm = forced_gm > 0 ? forced_gm : 8;
+            while (gm > 1 && m_tiles % gm) --gm;
+            const int nl = n_tiles_pad / 8;
+            int gn = forced_gn > 0 ? forced_gn : 12;
+            if (gn > nl) gn = nl;
+            if (gm > 1 && gn <= 255 && gm <= 255) {
+                map_mode |= (gm << 16) | (gn << 24);
+                g2 = dim3((unsigned)(8 * ((nl + gn - 1) / gn * gn) * m_tiles));
+            }
+        }
         static const int ablate = getenv("PPLHIP_GEMM_ABLATE") ? atoi(getenv("PPLHIP_GEMM_ABLATE")) : 0;  // diagnosis only: wrong results
         map_mode |= ablate << 8;
         static const int forced_st = getenv("PPLHIP_GEMM_STAGES") ? atoi(getenv("PPLHIP_GEMM_STAGES")) : 0;

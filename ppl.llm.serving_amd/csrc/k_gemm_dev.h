@@ -110,8 +110,18 @@ __device__ __forceinline__ void gemm_dma_body(const uint16_t* __restrict__ x, co
         mt = xcd + 8 * (slot % mg);
         nt = slot / mg;
     } else {
-        nt = xcd + 8 * (slot / m_tiles);
-        mt = slot % m_tiles;
+        // super-tiles of gn (n) x gm (m) tiles, m fastest inside, super-tiles m-major (gm = m_tiles: the plain n-major walk).  The ~96 blocks
+        // an XCD runs at a time then share gn weight and gm activation tiles per K step (k_gemm.hip, gemm_w8_dma256_kernel)
+        const int gm = (map_mode >> 16) & 0xff, gn = (map_mode >> 24) & 0xff;
+        if (gm == 0) {
+            nt = xcd + 8 * (slot / m_tiles);
+            mt = slot % m_tiles;
+        } else {
+            const int per_super = gn * gm, sm_count = m_tiles / gm;
+            const int sup = slot / per_super, within = slot % per_super;
+            nt = xcd + 8 * ((sup / sm_count) * gn + within / gm);
+            mt = (sup % sm_count) * gm + within % gm;
+        }
     }
     if (nt >= n_tiles) return;
     const int n0 = nt * G_BN;

@@ -292,13 +292,18 @@ __global__ __launch_bounds__(512) void gemm_i8_pc_kernel(const int8_t* __restric
 template <int EPI, int ST>
 __global__ __launch_bounds__(512) void gemm_i8_256_kernel(const int8_t* __restrict__ xq, const float* __restrict__ sx,
                                                           const int8_t* __restrict__ w, const uint16_t* __restrict__ scale, int64_t M,
-                                                          int N, int K, void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles) {
+                                                          int N, int K, void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles,
+                                                          int gn, int gm) {
     extern __shared__ __attribute__((aligned(16))) char smem_i8[];  // ST x (X 16 KiB) then ST x (W 16 KiB)
     constexpr int TILE = 256 * 64;
+    // XCD id % 8 walks its weight tiles in super-tiles of gn (n) x gm (m) tiles (k_gemm.hip, gemm_w8_dma256_kernel): the blocks it runs at a
+    // time share gn weight and gm activation tiles per K step
     const int id = blockIdx.x;
     const int xcd = id & 7, slot = id >> 3;
-    const int nt = xcd + 8 * (slot / m_tiles);
-    const int mt = slot % m_tiles;
+    const int per_super = gn * gm, sm_count = m_tiles / gm;
+    const int sup = slot / per_super, within = slot % per_super;
+    const int nt = xcd + 8 * ((sup / sm_count) * gn + within / gm);
+    const int mt = (sup % sm_count) * gm + within % gm;
     if (nt >= n_tiles) return;
     const int n0 = nt * 256;
     const int64_t m0 = (int64_t)mt * 256;
@@ -502,9 +507,16 @@ hipError_t launch_linear_i8(hipStream_t s, const int8_t* xq, const float* sx, co
 #undef A2
                 attr2[dev & 63] = true;
             }
-            dim3 g2((unsigned)((nt2 + 7) / 8 * 8 * mt2));
-#define L2(E) do { if (st256 == 3) hipLaunchKernelGGL((gemm_i8_256_kernel<E, 3>), g2, dim3(512), lds2, s, xq, sx, w, scale, M, N, K, y, ldy, nt2, mt2); \
-                   else hipLaunchKernelGGL((gemm_i8_256_kernel<E, 4>), g2, dim3(512), lds2, s, xq, sx, w, scale, M, N, K, y, ldy, nt2, mt2); } while (0)
+            static const int forced_gm = getenv("PPLHIP_GEMM256_GM") ? atoi(getenv("PPLHIP_GEMM256_GM")) : 0;
+            static const int forced_gn = getenv("PPLHIP_GEMM256_GN") ? atoi(getenv("PPLHIP_GEMM256_GN")) : 0;
+            const int nl = (nt2 + 7) / 8;
+            int gm = forced_gm > 0 ? forced_gm : 4;
+            while (gm > 1 && mt2 % gm) --gm;
+            int gn = forced_gn > 0 ? forced_gn : 8;
+            if (gn > nl) gn = nl;
+            dim3 g2((unsigned)(8 * ((nl + gn - 1) / gn * gn) * mt2));
+#define L2(E) do { if (st256 == 3) hipLaunchKernelGGL((gemm_i8_256_kernel<E, 3>), g2, dim3(512), lds2, s, xq, sx, w, scale, M, N, K, y, ldy, nt2, mt2, gn, gm); \
+                   else hipLaunchKernelGGL((gemm_i8_256_kernel<E, 4>), g2, dim3(512), lds2, s, xq, sx, w, scale, M, N, K, y, ldy, nt2, mt2, gn, gm); } while (0)
             if (epi == EPI_F32) L2(EPI_F32); else if (epi == EPI_F16) L2(EPI_F16); else L2(EPI_SWIGLU);
 #undef L2
             return hipGetLastError();

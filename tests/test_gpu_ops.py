@@ -88,6 +88,7 @@ def test_rmsnorm(hidden, skip):
 @pytest.mark.parametrize("M,N,K", [(1, 128, 128), (5, 384, 256), (130, 320, 128), (64, 512, 1376), (257, 1024, 4096),
                                    (33, 1024, 704), (2100, 1284, 512), (100, 384, 4096), (200, 260, 2048), (1024, 1536, 1024),
                                    (4100, 1092, 256),    # M >= 4096: the 256 x 256 tile kernel (prefill steps)
+                                   (4608, 5120, 128), (8192, 2304, 64),   # its super-tile block order: 18 x 20 tiles (3 x 3 super-tiles), 32 x 9 (4 x 2, padded share)
                                    # per-rank shapes of BASELINE configs 3 / 4: 13B/TP2 wqkv and w2, 70B/TP8 wqkv, wo-like and w2
                                    (300, 7680, 5120), (300, 5120, 6912), (256, 1280, 8192), (64, 8192, 1024), (130, 8192, 3584)])
 def test_linear(wq, M, N, K):
