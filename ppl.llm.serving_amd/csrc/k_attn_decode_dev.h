@@ -76,16 +76,42 @@ __device__ __forceinline__ void attn_decode_body(const uint16_t* __restrict__ qk
     const uint16_t* vsbase = ksbase + kv.ssKV;
     const int64_t row_bytes = kv.sN * C::ELT;
 
+    // Paged cache, power-of-two pages: the wave keeps 64 consecutive page ids of the request in ONE register (lane j: page pg0 + j) and
+    // looks them up with ds_bpermute, instead of a dependent page-table load in front of every group of KV loads.  The window moves
+    // (one dependent load) when the wave's tokens leave it: every 1024 tokens at 16-token pages.
+    // (page ids as 32-bit numbers: pages of >= 4 tokens in a slab that fits 288 GB stay far below 2^31)
+    const bool lane_pages = kv.mode == 1 && kv.page_shift >= 2;
+    const int64_t* const page_row = cache_indices + b * max_pages;
+    int64_t pg0 = 0;
+    int page_reg = 0;
     const int64_t stride = (int64_t)nw * TPW * DEC_UNROLL;
-    for (int64_t t0 = tbeg + (int64_t)wave * TPW * DEC_UNROLL; t0 < tend; t0 += stride) {
+    const int64_t tfirst = tbeg + (int64_t)wave * TPW * DEC_UNROLL;
+    if (lane_pages && tfirst < tend) {
+        pg0 = tfirst >> kv.page_shift;
+        const int64_t pj = pg0 + lane;
+        page_reg = (int)page_row[pj < max_pages ? pj : max_pages - 1];
+    }
+    for (int64_t t0 = tfirst; t0 < tend; t0 += stride) {
         uint4 kraw[DEC_UNROLL], vraw[DEC_UNROLL];
         uint32_t ksc[DEC_UNROLL], vsc[DEC_UNROLL];
         bool valid[DEC_UNROLL];
+        if (lane_pages && ((t0 + TPW * DEC_UNROLL - 1) >> kv.page_shift) - pg0 > 63) {  // wave-uniform
+            pg0 = t0 >> kv.page_shift;
+            const int64_t pj = pg0 + lane;
+            page_reg = (int)page_row[pj < max_pages ? pj : max_pages - 1];
+        }
 #pragma unroll
         for (int u = 0; u < DEC_UNROLL; ++u) {
             const int64_t tok = t0 + u * TPW + g;
             valid[u] = tok < tend;
-            const int64_t slot = kv_slot(kv, cache_indices, max_pages, b, valid[u] ? tok : tbeg);
+            int64_t slot;
+            if (lane_pages) {
+                const int64_t tk = valid[u] ? tok : t0;
+                const int pid = __shfl(page_reg, (int)((tk >> kv.page_shift) - pg0), 64);
+                slot = ((int64_t)pid << kv.page_shift) + (tk & (int64_t)(kv.page_size - 1));
+            } else {
+                slot = kv_slot(kv, cache_indices, max_pages, b, valid[u] ? tok : tbeg);
+            }
             kraw[u] = kv_stream_load(reinterpret_cast<const uint4*>(kbase + slot * row_bytes));
             vraw[u] = kv_stream_load(reinterpret_cast<const uint4*>(vbase + slot * row_bytes));
             if constexpr (QBIT == 8) {

@@ -520,7 +520,8 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         // (mode 1) by 2-4 % on every layer shape
         int map_mode = (forced == 1 && m_tiles % 8 == 0) ? 1 : 0;
         dim3 g2 = map_mode == 1 ? dim3((unsigned)(n_tiles * m_tiles)) : grid;
-        if (map_mode == 0 && m_tiles > 8) {
+        static const bool force_super = getenv("PPLHIP_GEMM128_GM") != nullptr;  // experiments at M <= 1024
+        if (map_mode == 0 && (m_tiles > 8 || force_super)) {
             // more than 8 activation tiles (M > 1024): walk the XCD's weight tiles in super-tiles of 12 (n) x 8 (m) -- at M = 1024 the
             // plain order already is that shape; at M = 8192 it degenerates to 1.5 weight tiles x 64 activation tiles in flight per XCD
             static const int forced_gm = getenv("PPLHIP_GEMM128_GM") ? atoi(getenv("PPLHIP_GEMM128_GM")) : 0;
