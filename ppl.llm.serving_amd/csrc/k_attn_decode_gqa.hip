@@ -125,6 +125,15 @@ __global__ __launch_bounds__(GQ_THREADS) void attn_decode_gqa_kernel(const uint1
     int vkey_l[PPL], vpc_l[PPL];
 #pragma unroll
     for (int j = 0; j < PPL; ++j) { vkey_l[j] = (lane + 64 * j) / LPT; vpc_l[j] = (lane + 64 * j) % LPT; }
+    // paged cache: the page id of the wave's NEXT sub-tile is fetched (one scalar load) while the current one is being loaded, so the
+    // page-table latency never sits in front of the KV loads (the wave's sub-tiles are GQ_WAVES x 16 keys apart, in call order)
+    const int64_t* const page_row = cache_indices + b * max_pages;
+    auto page_of = [&](int64_t kb) -> int64_t {
+        const int64_t kbc = kb < tend ? kb : ((tend - 1) & ~(int64_t)15);
+        return kv.page_shift >= 0 ? (kbc >> kv.page_shift) : kbc / kv.page_size;
+    };
+    int64_t pid_next = 0;
+    if (MODE == 1 && uniform_rows && tbeg < tend) pid_next = page_row[page_of(tbeg + (int64_t)wave * 16)];
     auto load_sub = [&](int p, int64_t kb) {
         // prefetches past the range re-read the range's last sub-tile (never consumed); rows past `tend` inside the last
         // sub-tile are clamped to its last valid row and masked in the softmax
@@ -136,7 +145,8 @@ __global__ __launch_bounds__(GQ_THREADS) void attn_decode_gqa_kernel(const uint1
             if (MODE == 0) slot_b = slot0 + kbc;
             else {
                 const int64_t pg = kv.page_shift >= 0 ? (kbc >> kv.page_shift) : kbc / kv.page_size;
-                slot_b = cache_indices[b * max_pages + pg] * kv.page_size + (kbc - pg * kv.page_size);
+                slot_b = pid_next * kv.page_size + (kbc - pg * kv.page_size);
+                pid_next = page_row[page_of(kb + 16 * GQ_WAVES)];
             }
             const char* kp = kbase + slot_b * rowb;
             const char* vp = vbase + slot_b * rowb;

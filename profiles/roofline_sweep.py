@@ -30,6 +30,9 @@ def heuristic_split(B, kv, H, Hkv):
     return 1
 
 
+PAGE = int(os.environ.get("SWEEP_PAGE", "0"))  # SWEEP_PAGE=16: paged cache (shuffled 16-token pages) instead of contiguous slots
+
+
 def run(B, KV, H, HKV, split, iters=64, warm=8):
     N = B * KV
     cache = torch.randint(-127, 128, (2 * HKV * N * D,), dtype=torch.int8, device="cuda")
@@ -40,12 +43,17 @@ def run(B, KV, H, HKV, split, iters=64, warm=8):
     seq = torch.arange(B + 1, device="cuda", dtype=torch.int64)
     sp = torch.full((B,), KV - 1, device="cuda", dtype=torch.int64)
     ci = torch.arange(B, device="cuda", dtype=torch.int64) * KV
+    mp = 0
+    if PAGE:
+        assert KV % PAGE == 0
+        mp = KV // PAGE
+        ci = torch.randperm(N // PAGE, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)).to(torch.int64).reshape(B, mp).contiguous()
     v = m.KvView()
     v.cache, v.scale, v.max_tokens, v.num_layers, v.kv_heads, v.head_dim = cache.data_ptr(), scale.data_ptr(), N, 1, HKV, D
-    v.quant_bit, v.quant_group, v.layout, v.mode, v.page_size, v.layer = 8, 8, 3, 0, 0, 0
+    v.quant_bit, v.quant_group, v.layout, v.mode, v.page_size, v.layer = 8, 8, 3, (1 if PAGE else 0), PAGE, 0
 
     def call():
-        return m.lib().pplhip_op_attention(None, qkv.data_ptr(), C.byref(v), seq.data_ptr(), sp.data_ptr(), ci.data_ptr(), 0, B, B, B, 1,
+        return m.lib().pplhip_op_attention(None, qkv.data_ptr(), C.byref(v), seq.data_ptr(), sp.data_ptr(), ci.data_ptr(), mp, B, B, B, 1,
                                            KV, H, split, ws.data_ptr(), ws.numel() * 4, out.data_ptr())
     for _ in range(warm):
         assert call() == 0
