@@ -549,7 +549,7 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         static const int forced_split = getenv("PPLHIP_GEMM_SPLITK") ? atoi(getenv("PPLHIP_GEMM_SPLITK")) : 0;
         const int64_t tiles = (int64_t)n_tiles * m_tiles;
         // (also at larger M when a tensor-parallel slice leaves fewer output tiles than CUs)
-        if (ws && ((M <= 256 && tiles < 512) || tiles < 200)) {
+        if (ws && ((M <= 256 && tiles < 512) || tiles < 200 || forced_split > 0)) {
             // enough blocks to fill the chip, but every split writes an fp32 slab of the whole output: keep >= min_kt K
             // tiles per split (measured at M = 64 / 256 on the 70B/TP8 shapes and M = 1024 on 7B/TP8 slices)
             static const int env_minkt = getenv("PPLHIP_GEMM_MINKT") ? atoi(getenv("PPLHIP_GEMM_MINKT")) : 0;
