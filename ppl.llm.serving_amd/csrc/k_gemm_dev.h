@@ -236,7 +236,8 @@ __device__ __forceinline__ void gemm_dma_body(const uint16_t* __restrict__ x, co
         const int younger = (ktiles - 1 - t) < (D - 1) ? (ktiles - 1 - t) : (D - 1);
         if constexpr (WL != 5) {   // every wave issues PT = X_DMA + W_DMA DMA instructions per tile
             constexpr int PT = X_DMA + W_DMA;
-            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PT) : "memory");
+            if (map_mode & 0x200) {}  // ablation 2 (PPLHIP_GEMM_ABLATE=2, wrong results): the DMA is issued but never waited for
+            else if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PT) : "memory");
             else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PT) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
