@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const uint16_t* __restrict__ 
 
 // stand-alone launch of the tile body (k_gemm_dev.h)
 template <int WQ, int EPI, int G_ST, int WL>
-__global__ __launch_bounds__(WL == 5 ? 512 : 256) void gemm_dma_kernel(const uint16_t* __restrict__ x, const void* __restrict__ wv,
+__global__ __launch_bounds__(WL == 6 ? 768 : (WL == 5 ? 512 : 256)) void gemm_dma_kernel(const uint16_t* __restrict__ x, const void* __restrict__ wv,
                                                              const uint16_t* __restrict__ scale, int64_t M, int N, int K,
                                                              void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles,
                                                              int map_mode, int kt_per_split, float* __restrict__ ws) {
@@ -580,9 +580,12 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         // per SIMD from the one block, the DMA issue runs beside the MFMA stream: wo 59 -> 46 us, w2 120 -> 95 us at
         // M = 1024); more blocks: 4 waves of 32(n) x 128(m), two blocks per CU (the specialised form is not faster there)
         static const int forced_wl = getenv("PPLHIP_GEMM_WL") ? atoi(getenv("PPLHIP_GEMM_WL")) : 0;
-        const int wl = (forced_wl == 1 || forced_wl == 5) ? forced_wl : (tiles * splits <= 256 ? 5 : 1);
+        int wl = (forced_wl == 1 || forced_wl == 5) ? forced_wl : (tiles * splits <= 256 ? 5 : 1);
+        // W8, one block per CU: eight consumer waves, each group multiplying one of the two k-steps of a tile (w2 at M = 1024: 100 -> 96 us)
+        if ((forced_wl == 6 || (forced_wl == 0 && wl == 5)) && wq_bit == 8 && stages >= 3 && splits == 1) wl = 6;
 #define DMA_LAUNCH(WQ, O32, ST)                                                                                     \
-    do { if (wl == 5) hipLaunchKernelGGL((gemm_dma_kernel<WQ, O32, ST, 5>), g2, dim3(512), 0, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles, map_mode, kt_per, ws); \
+    do { if constexpr (WQ == 8 && ST >= 3) { if (wl == 6) { hipLaunchKernelGGL((gemm_dma_kernel<WQ, O32, ST, 6>), g2, dim3(768), 0, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles, map_mode, kt_per, ws); break; } } \
+         if (wl == 5) hipLaunchKernelGGL((gemm_dma_kernel<WQ, O32, ST, 5>), g2, dim3(512), 0, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles, map_mode, kt_per, ws); \
          else hipLaunchKernelGGL((gemm_dma_kernel<WQ, O32, ST, 1>), g2, block, 0, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles, map_mode, kt_per, ws); } while (0)
 #define DMA_STAGES(WQ, O32)                                                                                         \
     do { if (stages == 2) DMA_LAUNCH(WQ, O32, 2); else if (stages == 3) DMA_LAUNCH(WQ, O32, 3); else DMA_LAUNCH(WQ, O32, 4); } while (0)

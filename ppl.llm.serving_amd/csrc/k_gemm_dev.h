@@ -73,6 +73,8 @@ constexpr int W4_MAXG = 64;  // W4: quantisation groups (of 128 along K) whose s
 // WL = wave layout of the 128x128x64 block tile:
 //   0: 4 waves, 2x2, each 64(n) x 64(m);  1: 4 waves, 4x1, each 32(n) x 128(m) x k64;
 //   5: 8 waves: 4 consumers with the layout of 1 and 4 producers that do nothing but issue the ring's LDS-DMA;
+//   6: 12 waves: 8 consumers -- the four of 5 twice, group h multiplying only k-step h of every K tile (two consumer waves per SIMD whose
+//      read / convert / MFMA chains overlap), partial sums added through LDS at the end -- and 4 producers; needs G_ST >= 3;
 // WQ = 8: int8 weights + per-channel scale; WQ = 0: fp16; WQ = 4: int4, group 128
 // LDS bytes gemm_dma_body needs
 template <int WQ, int G_ST>
@@ -128,8 +130,10 @@ __device__ __forceinline__ void gemm_dma_body(const uint16_t* __restrict__ x, co
     const int64_t m0 = (int64_t)mt * G_BM;
 
     // WL 5: waves 4..7 only issue the LDS-DMA of the ring (producers), waves 0..3 only multiply (consumers, layout of WL 1)
-    const bool producer = WL == 5 && threadIdx.x >= 256;
-    const int tid = WL == 5 ? (threadIdx.x & 255) : threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr bool PC = WL == 5 || WL == 6;  // producer / consumer forms
+    const bool producer = PC && threadIdx.x >= (WL == 6 ? 512 : 256);
+    const int tid = PC ? (threadIdx.x & 255) : threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kh = WL == 6 ? (int)((threadIdx.x >> 8) & 1) : 0;  // WL 6: the k-step of every tile this consumer multiplies
     const int l15 = lane & 15, kq = lane >> 4;
     // WL 1: every wave owns 32 weight rows and all 128 activation rows of the tile, so each weight fragment is converted
     // (int8/int4 -> fp16) by exactly one wave and feeds 8 MFMAs; WL 0 converts every fragment in two waves for 4 MFMAs
@@ -212,11 +216,11 @@ __device__ __forceinline__ void gemm_dma_body(const uint16_t* __restrict__ x, co
     }
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        if (d < ktiles && (WL != 5 || producer)) issue(d, (kt0 + d) * G_BK);
+        if (d < ktiles && (!PC || producer)) issue(d, (kt0 + d) * G_BK);
     }
     int st = 0, stn = D;  // stage of tile t, stage of tile t+D
     h2 gsc[NI];           // W4: this lane's row scales of the current group
-    if (WL == 5 && producer) {
+    if (PC && producer) {
         // producer waves: wait for their own pieces of tile t, meet the consumers at the barrier, refill the freed stage.
         // The LDS-DMA issue (~100 cycles per piece for the issuing wave) now runs beside the consumers' MFMA stream on
         // the SIMD instead of in front of it.
@@ -230,11 +234,12 @@ __device__ __forceinline__ void gemm_dma_body(const uint16_t* __restrict__ x, co
             if (t + D < ktiles) issue(stn, (kt0 + t + D) * G_BK);
             stn = stn == G_ST - 1 ? 0 : stn + 1;
         }
+        if constexpr (WL == 6) { __syncthreads(); __syncthreads(); }  // the consumers' two barriers around the partial-sum exchange
         return;
     }
     for (int t = 0; t < ktiles; ++t) {
         const int younger = (ktiles - 1 - t) < (D - 1) ? (ktiles - 1 - t) : (D - 1);
-        if constexpr (WL != 5) {   // every wave issues PT = X_DMA + W_DMA DMA instructions per tile
+        if constexpr (!PC) {   // every wave issues PT = X_DMA + W_DMA DMA instructions per tile
             constexpr int PT = X_DMA + W_DMA;
             if (map_mode & 0x200) {}  // ablation 2 (PPLHIP_GEMM_ABLATE=2, wrong results): the DMA is issued but never waited for
             else if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PT) : "memory");
@@ -242,7 +247,7 @@ __device__ __forceinline__ void gemm_dma_body(const uint16_t* __restrict__ x, co
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();  // tile t is published; the stage read during iteration t-1 (== stage of tile t+D) is free
-        if constexpr (WL != 5) if (t + D < ktiles && !(map_mode & 0x100)) issue(stn, (kt0 + t + D) * G_BK);  // 0x100: ablation (PPLHIP_GEMM_ABLATE)
+        if constexpr (!PC) if (t + D < ktiles && !(map_mode & 0x100)) issue(stn, (kt0 + t + D) * G_BK);  // 0x100: ablation (PPLHIP_GEMM_ABLATE)
         const uint16_t* xs = Xs0 + st * (G_BM * G_BK);
         const char* wq = Wq0 + st * W_STAGE;
         st = st == G_ST - 1 ? 0 : st + 1;
@@ -271,7 +276,8 @@ __device__ __forceinline__ void gemm_dma_body(const uint16_t* __restrict__ x, co
             }
         }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int kx = 0; kx < (WL == 6 ? 1 : 2); ++kx) {
+            const int ks = WL == 6 ? kh : kx;
             h8 a[NI], bfr[NJ];
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
@@ -302,6 +308,27 @@ __device__ __forceinline__ void gemm_dma_body(const uint16_t* __restrict__ x, co
         }
     }
 
+    if constexpr (WL == 6) {
+        // the k-step-1 group hands its partial sums to the k-step-0 group through the (now idle) ring: [wave][i][j][lane] float4
+        float4* red = reinterpret_cast<float4*>(smem);
+        __syncthreads();  // every consumer is past its last fragment read
+        if (kh == 1) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    red[((wave * NI + i) * NJ + j) * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+        __syncthreads();
+        if (kh == 1) return;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float4 o = red[((wave * NI + i) * NJ + j) * 64 + lane];
+                acc[i][j][0] += o.x; acc[i][j][1] += o.y; acc[i][j][2] += o.z; acc[i][j][3] += o.w;
+            }
+    }
     if (n_splits > 1) {  // fp32 partial slab [split][M][N]
         float* slab = ws + (int64_t)split_id * M * N;
 #pragma unroll

@@ -20,7 +20,7 @@ constexpr int WD_XP = WD_XB / 1024;       // = 16 one-KiB DMA pieces
 // 16 waves: 12 consumers (wave w: weight rows 32 w .. + 32 x all 128 activation rows) and 4 producers (one per SIMD) that do nothing
 // but keep the ST-stage ring filled.
 // NC consumer waves: block tile 128 (m) x 32 NC (n); NC = 12, 11, 10 so that the tile count fits whole rounds of 256 blocks
-template <int EPI, int ST, int NC>
+template <int EPI, int ST, int NC, int ABL = 0>
 __global__ __launch_bounds__((NC + WD_NP) * 64) void gemm_w8_wide_kernel(const uint16_t* __restrict__ x, const int8_t* __restrict__ w,
                                                                   const uint16_t* __restrict__ scale, int64_t M, int N, int K,
                                                                   void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles) {
@@ -93,8 +93,8 @@ __global__ __launch_bounds__((NC + WD_NP) * 64) void gemm_w8_wide_kernel(const u
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            __syncthreads();  // tile t is published; the stage the consumers read during iteration t - 1 is free
-            if (t + D < ktiles) WD_PRODUCE(t + D, stn);
+            if (!(ABL & 8)) __syncthreads();  // tile t is published; the stage the consumers read during iteration t - 1 is free
+            if (t + D < ktiles && !(ABL & 1)) WD_PRODUCE(t + D, stn);
             stn = stn == ST - 1 ? 0 : stn + 1;
         }
 #undef WD_PRODUCE
@@ -111,7 +111,7 @@ __global__ __launch_bounds__((NC + WD_NP) * 64) void gemm_w8_wide_kernel(const u
         for (int j = 0; j < 8; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
     int st = 0;
     for (int t = 0; t < ktiles; ++t) {
-        __syncthreads();  // tile t is published
+        if (!(ABL & 8)) __syncthreads();  // tile t is published
         const uint16_t* xs = reinterpret_cast<const uint16_t*>(Xs0 + st * WD_XB);
         const char* wq = Wq0 + st * WD_WB;
         st = st == ST - 1 ? 0 : st + 1;
@@ -125,11 +125,14 @@ __global__ __launch_bounds__((NC + WD_NP) * 64) void gemm_w8_wide_kernel(const u
         for (int ks = 0; ks < 2; ++ks) {
             h8 a[2], bfr[8];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = cvt_i8x8_f16(ks == 0 ? make_uint2(wraw[i].x, wraw[i].y) : make_uint2(wraw[i].z, wraw[i].w));
+            for (int i = 0; i < 2; ++i) {
+                if constexpr (ABL & 2) a[i] = __builtin_bit_cast(h8, make_uint4(wraw[i].x, wraw[i].y, wraw[i].z ^ ks, wraw[i].w));
+                else a[i] = cvt_i8x8_f16(ks == 0 ? make_uint2(wraw[i].x, wraw[i].y) : make_uint2(wraw[i].z, wraw[i].w));
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int row = j * 16 + l15;
-                bfr[j] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&xs[row * G_BK + g_swz(row, ks * 4 + kq) * 8]));
+                bfr[j] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&xs[((ABL & 4) ? 0 : row * G_BK) + g_swz(row, ks * 4 + kq) * 8]));
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -184,6 +187,13 @@ hipError_t launch_linear_w8_wide(hipStream_t s, const uint16_t* x, const int8_t*
         attr_dev[dev & 63] = true;
     }
     dim3 grid((unsigned)((n_tiles + 7) / 8 * 8 * m_tiles));
+#ifdef WD_ABLATE_BUILD  // diagnosis (wrong results): PPLHIP_GEMM_WIDE_ABLATE = 1 no refills, 2 no conversion, 4 one activation row, 8 no barriers
+    static const int abl = getenv("PPLHIP_GEMM_WIDE_ABLATE") ? atoi(getenv("PPLHIP_GEMM_WIDE_ABLATE")) : 0;
+#define WD_AB(A) if (abl == A) { (void)hipFuncSetAttribute((const void*)gemm_w8_wide_kernel<EPI_F16, ST, 12, A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((gemm_w8_wide_kernel<EPI_F16, ST, 12, A>), grid, dim3((12 + WD_NP) * 64), lds, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles); return hipGetLastError(); }
+    WD_AB(1) WD_AB(2) WD_AB(3) WD_AB(4) WD_AB(6) WD_AB(7) WD_AB(8) WD_AB(15)
+#undef WD_AB
+#endif
 #define WD_L(E, C) hipLaunchKernelGGL((gemm_w8_wide_kernel<E, ST, C>), grid, dim3((C + WD_NP) * 64), lds, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles)
 #define WD_E(C) do { if (epi == EPI_F32) WD_L(EPI_F32, C); else if (epi == EPI_F16) WD_L(EPI_F16, C); else WD_L(EPI_SWIGLU, C); } while (0)
     WD_E(12);
