@@ -519,7 +519,7 @@ def main():
             per_layer = (H + 2 * Hkv) * D * hd_ + hd_ * H * D + 2 * it_ * hd_ + hd_ * it_
             flops = 2.0 * B * (desc.num_layers * per_layer + (desc.vocab_size // tp) * hd_)
             tf = flops / (gemm_ms_per_step * 1e-3) / 1e12
-            res["roofline_gemm"] = {"kernel": "gemm_dma_kernel (128x128x64 LDS-DMA tiles)", "bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0,
+            res["roofline_gemm"] = {"kernel": "gemm_w8_wide_kernel (128x384x64, wqkv / w13) + gemm_dma_kernel (128x128x64, wo / w2), LDS-DMA rings", "bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0,
                                     "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "flops_per_step": flops,
                                     "note": "dense fp16 MFMA peak; durations from the bracketed extra steps (breakdown_ms_per_step.gemm)"}
         res.update(extra)
