@@ -127,6 +127,36 @@ def test_linear(wq, M, N, K):
         close_f16(got, want, rel=rel, abs_=rel * mag * (0.25 if wq == 4 else 0.05) + 1e-5)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_linear_random_shapes_w8(seed):
+    """pplhip_op_linear W8A16 over random shapes around the dispatcher's thresholds (skinny / 128 x 128 with and without split-K and
+    producers / 128 x 384 producer-consumer / 256 x 256 with its super-tile order), against the oracle on the whole output."""
+    m = load_pplhip()
+    rng = np.random.RandomState(1000 + seed)
+    cases = []
+    for _ in range(5):
+        M = int(rng.choice([rng.randint(1, 40), rng.randint(100, 600), rng.randint(512, 1300), rng.randint(1300, 4200), rng.randint(4096, 5000)]))
+        N = int(rng.choice([rng.randint(16, 300), rng.randint(1000, 4200), rng.randint(8192, 13000)])) // 4 * 4
+        K = int(rng.choice([64, 128, 192, 320, 704])) if M * N > 2e7 else int(rng.randint(1, 24)) * 64
+        cases.append((M, N, K))
+    for M, N, K in cases:
+        x = f16(rng.randn(M, K))
+        w = rng.randint(-127, 128, size=(N, K)).astype(np.int8)
+        scale = f16(0.0005 * (0.5 + rng.rand(N)))
+        want = np.empty((M, N), dtype=np.float32)
+        xs = x.astype(np.float32)
+        ref.lib().ref_linear_raw(xs.ctypes.data, w.ctypes.data, scale.ctypes.data, 8, 128, M, N, K, want.ctypes.data, 0)
+        y = torch.empty((M, N), dtype=torch.float16, device="cuda")
+        dx, dw, ds = dev(x), dev(w), dev(scale)
+        ck(m.lib().pplhip_op_linear(None, dx.data_ptr(), dw.data_ptr(), ds.data_ptr(), 8, 128, M, N, K, y.data_ptr(), 0))
+        got = y.float().cpu().numpy()
+        mag = np.abs(want).max()
+        try:
+            close_f16(got, want, rel=1.5e-3, abs_=1.5e-3 * mag * 0.05 + 1e-5)
+        except AssertionError as e:
+            raise AssertionError(f"shape M={M} N={N} K={K}: {e}")
+
+
 def test_silu_mul():
     m = load_pplhip()
     rng = np.random.RandomState(3)
