@@ -476,8 +476,8 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
     // W8A16 at 512 <= M < 4096 with N >= 8192 (wqkv / w13 of a decode step at batch ~1024): one 128 x 384 block per CU whose twelve
     // consumer waves share the activation tile (k_gemm_wide.hip) when its tiles fill the chip's rounds; PPLHIP_GEMM_WIDE=0: never
     static const int wide = getenv("PPLHIP_GEMM_WIDE") ? atoi(getenv("PPLHIP_GEMM_WIDE")) : 1;
-    if (wide && wq_bit == 8 && K % G_BK == 0 && M >= 512 && M < 4096 && N >= 8192) {
-        const int nc = linear_w8_wide_waves(M, N);
+    if (wide && wq_bit == 8 && K % G_BK == 0 && M >= 512 && (M < 4096 || wide == 2) && N >= 8192) {
+        const int nc = wide == 2 ? 12 : linear_w8_wide_waves(M, N);  // (2: experiments -- every eligible shape, any M)
         if (nc) return launch_linear_w8_wide(s, x, (const int8_t*)w, scale, M, N, K, y, ldy, epi, nc);
     }
     const int n_tiles = (N + G_BN - 1) / G_BN;
