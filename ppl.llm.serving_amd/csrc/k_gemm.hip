@@ -186,13 +186,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const uint16_t* __restrict__ 
 }
 
 // stand-alone launch of the tile body (k_gemm_dev.h)
-template <int WQ, int EPI, int G_ST, int WL>
+template <int WQ, int EPI, int G_ST, int WL, int BM = G_BM>
 __global__ __launch_bounds__(WL == 6 ? 768 : (WL == 5 ? 512 : 256)) void gemm_dma_kernel(const uint16_t* __restrict__ x, const void* __restrict__ wv,
                                                              const uint16_t* __restrict__ scale, int64_t M, int N, int K,
                                                              void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles,
                                                              int map_mode, int kt_per_split, float* __restrict__ ws) {
-    __shared__ __attribute__((aligned(16))) char smem[gemm_dma_lds_bytes<WQ, G_ST>()];
-    gemm_dma_body<WQ, EPI, G_ST, WL>(x, wv, scale, M, N, K, yv, ldy, n_tiles, m_tiles, map_mode, kt_per_split, ws, (int)blockIdx.x,
+    __shared__ __attribute__((aligned(16))) char smem[gemm_dma_lds_bytes<WQ, G_ST, BM>()];
+    gemm_dma_body<WQ, EPI, G_ST, WL, BM>(x, wv, scale, M, N, K, yv, ldy, n_tiles, m_tiles, map_mode, kt_per_split, ws, (int)blockIdx.x,
                                      (int)blockIdx.y, (int)gridDim.y, smem);
 }
 
@@ -464,7 +464,10 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
     if (wq_bit == 8 && K % 16) return hipErrorInvalidValue;
     if (wq_bit == 4 && (K % 32 || group % 32 || K % group)) return hipErrorInvalidValue;
     static const bool no_skinny = getenv("PPLHIP_GEMM_NOSKINNY") != nullptr, force_generic = getenv("PPLHIP_GEMM_GENERIC") != nullptr;
-    if (M <= 16 && !no_skinny) {  // above 16 rows the split-K tiled kernel is faster (profiles/gemm_microbench.py)
+    // the skinny kernel up to 3 rows; from 4 rows the half-height tile kernel (64 activation rows, split-K) is faster: 7B decode step at batch
+    // 4 / 8 / 12 / 16 3.64 / 3.90 / 4.40 / 4.74 -> 3.56 / 3.73 / 3.81 / 4.18 ms (profiles/small_batch_latency.py); PPLHIP_GEMV_MAX_M overrides
+    static const int gemv_max_m = getenv("PPLHIP_GEMV_MAX_M") ? atoi(getenv("PPLHIP_GEMV_MAX_M")) : 3;
+    if (M <= gemv_max_m && M <= 16 && !no_skinny) {
 #define GEMV_DISPATCH(WQ)                                                                                      \
     if (wq_bit == WQ)                                                                                          \
         return epi == EPI_F32 ? launch_gemv<WQ, EPI_F32>(s, x, w, scale, group, M, N, K, y, ldy)               \
@@ -581,11 +584,16 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         // M = 1024); more blocks: 4 waves of 32(n) x 128(m), two blocks per CU (the specialised form is not faster there)
         static const int forced_wl = getenv("PPLHIP_GEMM_WL") ? atoi(getenv("PPLHIP_GEMM_WL")) : 0;
         int wl = (forced_wl == 1 || forced_wl == 5) ? forced_wl : (tiles * splits <= 256 ? 5 : 1);
+        // 16 < M <= 64: half-height tiles (64 activation rows), 4-wave blocks
+        static const int forced_half = getenv("PPLHIP_GEMM_HALF") ? atoi(getenv("PPLHIP_GEMM_HALF")) : -1;
+        const bool half = forced_half >= 0 ? (forced_half == 1 && M <= 64) : M <= 64;  // 7B layer GEMMs at M = 64: 102 -> 84 us, M = 32: 90 -> 74 us
+        if (half) wl = 1;
         // W8, one block per CU: eight consumer waves, each group multiplying one of the two k-steps of a tile (w2 at M = 1024: 100 -> 96 us)
         if ((forced_wl == 6 || (forced_wl == 0 && wl == 5)) && wq_bit == 8 && stages >= 3 && splits == 1) wl = 6;
 #define DMA_LAUNCH(WQ, O32, ST)                                                                                     \
     do { if constexpr (WQ == 8 && ST >= 3) { if (wl == 6) { hipLaunchKernelGGL((gemm_dma_kernel<WQ, O32, ST, 6>), g2, dim3(768), 0, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles, map_mode, kt_per, ws); break; } } \
          if (wl == 5) hipLaunchKernelGGL((gemm_dma_kernel<WQ, O32, ST, 5>), g2, dim3(512), 0, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles, map_mode, kt_per, ws); \
+         else if (half) hipLaunchKernelGGL((gemm_dma_kernel<WQ, O32, ST, 1, 64>), g2, block, 0, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles, map_mode, kt_per, ws); \
          else hipLaunchKernelGGL((gemm_dma_kernel<WQ, O32, ST, 1>), g2, block, 0, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles, map_mode, kt_per, ws); } while (0)
 #define DMA_STAGES(WQ, O32)                                                                                         \
     do { if (stages == 2) DMA_LAUNCH(WQ, O32, 2); else if (stages == 3) DMA_LAUNCH(WQ, O32, 3); else DMA_LAUNCH(WQ, O32, 4); } while (0)

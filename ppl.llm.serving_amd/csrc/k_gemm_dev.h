@@ -77,13 +77,15 @@ constexpr int W4_MAXG = 64;  // W4: quantisation groups (of 128 along K) whose s
 //      read / convert / MFMA chains overlap), partial sums added through LDS at the end -- and 4 producers; needs G_ST >= 3;
 // WQ = 8: int8 weights + per-channel scale; WQ = 0: fp16; WQ = 4: int4, group 128
 // LDS bytes gemm_dma_body needs
-template <int WQ, int G_ST>
+template <int WQ, int G_ST, int BM = G_BM>
 constexpr int gemm_dma_lds_bytes() {
     constexpr int WB2 = WQ == 8 ? 2 : (WQ == 4 ? 1 : 4);
-    return G_ST * (G_BM * G_BK * 2 + G_BN * G_BK * WB2 / 2) + (WQ == 4 ? W4_MAXG * G_BN * 2 : 0);
+    return G_ST * (BM * G_BK * 2 + G_BN * G_BK * WB2 / 2) + (WQ == 4 ? W4_MAXG * G_BN * 2 : 0);
 }
 
-template <int WQ, int EPI, int G_ST, int WL>
+// BM = 64 (WL 1 only): half-height tile for 16 < M <= 64 -- half the activation bytes per stage and half the MFMAs of a 128-row tile whose
+// upper half would only repeat row M - 1
+template <int WQ, int EPI, int G_ST, int WL, int BM = G_BM>
 __device__ __forceinline__ void gemm_dma_body(const uint16_t* __restrict__ x, const void* __restrict__ wv,
                                               const uint16_t* __restrict__ scale, int64_t M, int N, int K, void* __restrict__ yv,
                                               int64_t ldy, int n_tiles, int m_tiles, int map_mode, int kt_per_split,
@@ -92,13 +94,14 @@ __device__ __forceinline__ void gemm_dma_body(const uint16_t* __restrict__ x, co
     constexpr int WB2 = WQ == 8 ? 2 : (WQ == 4 ? 1 : 4);   // half-bytes per weight element
     constexpr int W_STAGE = G_BN * G_BK * WB2 / 2;         // 8 KiB (int8) / 16 KiB (fp16) / 4 KiB (int4)
     constexpr int NT = 256;                                // threads that move tile pieces (WL 5: the 4 producer waves)
-    constexpr int X_DMA = G_BM * G_BK * 2 / (NT * 16);     // DMA instructions per wave per tile for X (4 or 2)
+    static_assert(BM == G_BM || (BM == 64 && WL == 1), "half-height tiles: 4-wave layout only");
+    constexpr int X_DMA = BM * G_BK * 2 / (NT * 16);       // DMA instructions per wave per tile for X (4; 2 at BM = 64)
     constexpr int W_DMA = W_STAGE / (NT * 16);             // ... for W (2 int8, 4 fp16, 1 int4)
     // (W4: W4_MAXG * G_BN * 2 more bytes for the group scales of this block's rows, [group][row])
     // smem: G_ST * (G_BM * G_BK * 2 + W_STAGE) + SC_BYTES bytes (per stage: X 16 KiB + W), 16-byte aligned, provided by the caller
     uint16_t* const Xs0 = reinterpret_cast<uint16_t*>(smem);
-    char* const Wq0 = smem + G_ST * G_BM * G_BK * 2;
-    uint16_t* const Sc = reinterpret_cast<uint16_t*>(smem + G_ST * (G_BM * G_BK * 2 + W_STAGE));
+    char* const Wq0 = smem + G_ST * BM * G_BK * 2;
+    uint16_t* const Sc = reinterpret_cast<uint16_t*>(smem + G_ST * (BM * G_BK * 2 + W_STAGE));
     const char* w = reinterpret_cast<const char*>(wv);
 
     // block -> tile.  map_mode 1 (m_tiles % 8 == 0): XCD x = id % 8 owns the activation row-tiles m == x (mod 8) and
@@ -127,7 +130,7 @@ __device__ __forceinline__ void gemm_dma_body(const uint16_t* __restrict__ x, co
     }
     if (nt >= n_tiles) return;
     const int n0 = nt * G_BN;
-    const int64_t m0 = (int64_t)mt * G_BM;
+    const int64_t m0 = (int64_t)mt * BM;
 
     // WL 5: waves 4..7 only issue the LDS-DMA of the ring (producers), waves 0..3 only multiply (consumers, layout of WL 1)
     constexpr bool PC = WL == 5 || WL == 6;  // producer / consumer forms
@@ -137,7 +140,7 @@ __device__ __forceinline__ void gemm_dma_body(const uint16_t* __restrict__ x, co
     const int l15 = lane & 15, kq = lane >> 4;
     // WL 1: every wave owns 32 weight rows and all 128 activation rows of the tile, so each weight fragment is converted
     // (int8/int4 -> fp16) by exactly one wave and feeds 8 MFMAs; WL 0 converts every fragment in two waves for 4 MFMAs
-    constexpr int NI = WL ? 2 : 4, NJ = WL ? 8 : 4;
+    constexpr int NI = WL ? 2 : 4, NJ = WL ? BM / 16 : 4;
     const int wn = WL ? wave : wave >> 1, wm = WL ? 0 : wave & 1;
     const int nb = wn * (NI * 16), mb = wm * (NJ * 16);  // row bases of this wave inside the tile
 
@@ -182,7 +185,7 @@ __device__ __forceinline__ void gemm_dma_body(const uint16_t* __restrict__ x, co
     const uint32_t wdst = __builtin_amdgcn_readfirstlane(lds_addr(Wq0) + wave * 1024);
     auto issue = [&](int stage, int k0) {
 #pragma unroll
-        for (int j = 0; j < X_DMA; ++j) glds16(xsrc[j] + k0, xdst + stage * (G_BM * G_BK * 2) + j * (NT * 16));
+        for (int j = 0; j < X_DMA; ++j) glds16(xsrc[j] + k0, xdst + stage * (BM * G_BK * 2) + j * (NT * 16));
 #pragma unroll
         for (int j = 0; j < W_DMA; ++j) glds16(wsrc[j] + k0 * WB2 / 2, wdst + stage * W_STAGE + j * (NT * 16));
     };
@@ -248,7 +251,7 @@ __device__ __forceinline__ void gemm_dma_body(const uint16_t* __restrict__ x, co
         }
         __syncthreads();  // tile t is published; the stage read during iteration t-1 (== stage of tile t+D) is free
         if constexpr (!PC) if (t + D < ktiles && !(map_mode & 0x100)) issue(stn, (kt0 + t + D) * G_BK);  // 0x100: ablation (PPLHIP_GEMM_ABLATE)
-        const uint16_t* xs = Xs0 + st * (G_BM * G_BK);
+        const uint16_t* xs = Xs0 + st * (BM * G_BK);
         const char* wq = Wq0 + st * W_STAGE;
         st = st == G_ST - 1 ? 0 : st + 1;
         stn = stn == G_ST - 1 ? 0 : stn + 1;
