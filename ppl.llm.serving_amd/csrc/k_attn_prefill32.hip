@@ -34,12 +34,16 @@ __device__ __forceinline__ uint2 p3_v_frag(const uint16_t* sub, int r0, int l15)
 }
 __device__ __forceinline__ int crow(int i, int hi) { return (i & 3) + 8 * (i >> 2) + 4 * hi; }
 
-template <int QBIT, int MODE, int NW, int ABL = 0>
+// SPLIT: the block handles the KV tiles of split blockIdx.y of gridDim.y only and writes unnormalised partial rows (O, m, l) to `ws`
+// ([token row][head][split][D + 2] floats, the layout of the decode kernels); attn_prefill32_reduce_kernel merges them.  For short new
+// suffixes behind a long cached prefix (a prefix-cache hit recomputes one page): a request is otherwise H blocks walking thousands of keys.
+template <int QBIT, int MODE, int NW, int ABL = 0, int SPLIT = 0>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_prefill32_kernel(const uint16_t* __restrict__ qkv, KvAddr kv,
                                                                     const int64_t* __restrict__ seq_starts,
                                                                     const int64_t* __restrict__ start_pos,
                                                                     const int64_t* __restrict__ cache_indices, int64_t max_pages,
-                                                                    int64_t b0, int H, int Hkv, int nreq, int nqb, uint16_t* __restrict__ out) {
+                                                                    int64_t b0, int H, int Hkv, int nreq, int nqb, uint16_t* __restrict__ out,
+                                                                    float* __restrict__ ws) {
     constexpr int D = P3_D;
     constexpr int P3_BM = NW * 32, P3_THREADS = NW * 64;  // NW waves x 32 query rows share the staged K / V tiles
     constexpr int ELT = QBIT == 8 ? 1 : 2;
@@ -175,11 +179,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }                                                                                                                      \
     } while (0)
 
-    P3_LOAD_TILE(0);
-    for (int tile = 0; tile < ntiles; ++tile) {
+    // SPLIT: tiles [tb, te) of this split (possibly none)
+    const int tb = SPLIT ? (int)((int64_t)ntiles * blockIdx.y / gridDim.y) : 0;
+    const int te = SPLIT ? (int)((int64_t)ntiles * (blockIdx.y + 1) / gridDim.y) : ntiles;
+    if (tb < te) P3_LOAD_TILE(tb);
+    for (int tile = tb; tile < te; ++tile) {
         const int64_t key0 = (int64_t)tile * P3_BN;
-        if (!(ABL & 2) || tile < 2) {   // dequantise the tile loaded during the previous iteration -> stage tile & 1
-            uint16_t* Kw = smem + (tile & 1) * (P3_KS_HALFS + P3_VS_HALFS);
+        if (!(ABL & 2) || tile < tb + 2) {   // dequantise the tile loaded during the previous iteration -> stage tile & 1
+            uint16_t* Kw = smem + ((tile - tb) & 1) * (P3_KS_HALFS + P3_VS_HALFS);
             uint16_t* Vw = Kw + P3_KS_HALFS;
             P3_STORE_ITEM(0, kr0, vr0, kc0, vc0);
             if constexpr (IPT >= 2) P3_STORE_ITEM(1, kr1, vr1, kc1, vc1);
@@ -191,8 +198,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         if (!(ABL & 8)) __syncthreads();  // tile `tile` is visible in stage tile & 1; every wave is past its reads of the other stage (tile - 1)
         // in flight during the MFMAs below.  UNCONDITIONAL (the last iteration re-reads its own tile and drops it): a conditional
         // refill made hipcc keep the fp16 build's staging arrays in scratch memory
-        if (!(ABL & 2)) P3_LOAD_TILE(tile + 1 < ntiles ? tile + 1 : tile);
-        const uint16_t* Ks = smem + (tile & 1) * (P3_KS_HALFS + P3_VS_HALFS);
+        if (!(ABL & 2)) P3_LOAD_TILE(tile + 1 < te ? tile + 1 : tile);
+        const uint16_t* Ks = smem + ((tile - tb) & 1) * (P3_KS_HALFS + P3_VS_HALFS);
         const uint16_t* Vs = Ks + P3_KS_HALFS;
         if (wave_active && key0 <= sp + wlast) {  // causal: a wave whose rows all end before this tile has nothing to add
             // ---- S^T = K . Q^T: two 32-key blocks ----------------------------------------------------------------------------
@@ -299,6 +306,22 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     // ---- epilogue: O / l, fp16; value i of channel block c = query wrow0 + crow(i, hi), channel 32 c + l31 ----------------------------
     if (!wave_active) return;
+    if constexpr (SPLIT) {
+        const float to_nat = 1.0f / sqrtf((float)D);  // the running maximum is in raw score units; the merge works on natural-log scores
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = crow(i, hi);
+            const float lr = __shfl(l, r, 64), mr = __shfl(m, r, 64);
+            const int64_t qrow_i = wrow0 + r;
+            if (qrow_i < seqlen) {
+                float* wrow = ws + (((seq_starts[b] + qrow_i) * H + hq) * (int64_t)gridDim.y + blockIdx.y) * (D + 2);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) wrow[c * 32 + l31] = o[c][i];
+                if (l31 == 0) { wrow[D] = mr * to_nat; wrow[D + 1] = lr; }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int r = crow(i, hi);
@@ -313,6 +336,23 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
 }
 
+// merges the splits of token rows [row0, row0 + gridDim.x / H): one block per (row, head), one thread per channel
+__global__ void attn_prefill32_reduce_kernel(const float* __restrict__ ws, int nsplit, int64_t row0, int H, uint16_t* __restrict__ out) {
+    constexpr int D = P3_D;
+    const int64_t bh = row0 * H + blockIdx.x;
+    const float* w = ws + bh * (int64_t)nsplit * (D + 2);
+    const int d = threadIdx.x;
+    float mm = -1e30f;
+    for (int sp = 0; sp < nsplit; ++sp) mm = fmaxf(mm, w[sp * (D + 2) + D]);
+    float ll = 0.f, o = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) {
+        const float a = __expf(w[sp * (D + 2) + D] - mm);
+        ll = fmaf(w[sp * (D + 2) + D + 1], a, ll);
+        o = fmaf(w[sp * (D + 2) + d], a, o);
+    }
+    out[bh * D + d] = f2h(o / ll);
+}
+
 #undef P3_LOAD_TILE
 #undef P3_LOAD_ITEM
 #undef P3_STORE_ITEM
@@ -323,9 +363,35 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
 hipError_t launch_attn_prefill32(hipStream_t s, const uint16_t* qkv, const KvAddr& kv, int quant_bit, const int64_t* seq_starts,
                                  const int64_t* start_pos, const int64_t* cache_indices, int64_t max_pages, int64_t b0, int64_t B,
-                                 int H, int Hkv, int D, int64_t max_seq_len, uint16_t* out) {
+                                 int H, int Hkv, int D, int64_t max_seq_len, uint16_t* out, int64_t max_kv_len, float* ws, size_t ws_bytes,
+                                 int64_t row0, int64_t nrows) {
     if (D != P3_D || (quant_bit != 0 && quant_bit != 8)) return hipErrorInvalidValue;
     if (B <= b0 || max_seq_len <= 0) return hipSuccess;
+    // Short new suffixes behind long caches (every request of the launch has <= 32 new tokens -- a prefix-cache hit recomputes one page --
+    // and there are too few (request, head) blocks to fill the chip): split the keys over gridDim.y blocks and merge (flash-decoding form).
+    // row0 / nrows: the token rows of these requests (they are contiguous in the step); ws: nrows x H x splits x (D + 2) floats.
+    static const int split_env = getenv("PPLHIP_P32_SPLIT") ? atoi(getenv("PPLHIP_P32_SPLIT")) : -1;  // 0: never; n > 1: force n
+    if (split_env != 0 && ws && nrows > 0 && max_seq_len <= 32 && (int64_t)(B - b0) * H < 256 && max_kv_len >= 1024) {
+        const int64_t blocks = (int64_t)(B - b0) * H, ntiles = (max_kv_len + P3_BN - 1) / P3_BN;
+        int64_t nsplit = (512 + blocks - 1) / blocks;
+        if (nsplit > ntiles / 4) nsplit = ntiles / 4;   // at least four 64-key tiles per split
+        if (nsplit > 32) nsplit = 32;
+        if (split_env > 1) nsplit = split_env;
+        while (nsplit > 1 && (size_t)nrows * H * nsplit * (P3_D + 2) * sizeof(float) > ws_bytes) --nsplit;
+        if (nsplit > 1) {
+            const int nreq = (int)(B - b0);
+            dim3 grid((unsigned)((int64_t)nreq * H), (unsigned)nsplit);
+#define P3_SPLIT(QB, MD) hipLaunchKernelGGL((attn_prefill32_kernel<QB, MD, 4, 0, 1>), grid, dim3(256), 0, s, qkv, kv, seq_starts, start_pos, \
+                                            cache_indices, max_pages, b0, H, Hkv, nreq, 1, out, ws)
+            if (quant_bit == 8) { if (kv.mode == 0) P3_SPLIT(8, 0); else P3_SPLIT(8, 1); }
+            else { if (kv.mode == 0) P3_SPLIT(0, 0); else P3_SPLIT(0, 1); }
+#undef P3_SPLIT
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(attn_prefill32_reduce_kernel, dim3((unsigned)(nrows * H)), dim3(P3_D), 0, s, ws, (int)nsplit, row0, H, out);
+            return hipGetLastError();
+        }
+    }
     // 8 waves (256 query rows per block: each staged K / V tile serves twice the rows) once the sequences are long enough: 8192 new
     // tokens 1002 vs 1043 us, 2048 over a 6144-token cache 481 vs 538 us, but 16 x 512 tokens 105 vs 101 us
     static const int nw_env = getenv("PPLHIP_P32_NW") ? atoi(getenv("PPLHIP_P32_NW")) : 0;
@@ -334,10 +400,10 @@ hipError_t launch_attn_prefill32(hipStream_t s, const uint16_t* qkv, const KvAdd
     const int nqb = (int)((max_seq_len + bm - 1) / bm), nreq = (int)(B - b0);
     dim3 grid((unsigned)((int64_t)nqb * nreq * H));
 #define P3_LAUNCH(QB, MD, NW_) hipLaunchKernelGGL((attn_prefill32_kernel<QB, MD, NW_>), grid, dim3(NW_ * 64), 0, s, qkv, kv, seq_starts, start_pos, \
-                                                  cache_indices, max_pages, b0, H, Hkv, nreq, nqb, out)
+                                                  cache_indices, max_pages, b0, H, Hkv, nreq, nqb, out, nullptr)
 #ifdef P3_ABLATE_BUILD  // diagnosis build (profiles/r03_prefill_attention_ablation.md): wrong results, same instruction stream otherwise
     static const int abl = getenv("PPLHIP_P32_ABLATE") ? atoi(getenv("PPLHIP_P32_ABLATE")) : 0;
-#define P3_ABL(A) if (abl == A && nw == 8) { hipLaunchKernelGGL((attn_prefill32_kernel<8, 0, 8, A>), grid, dim3(512), 0, s, qkv, kv, seq_starts, start_pos, cache_indices, max_pages, b0, H, Hkv, nreq, nqb, out); return hipGetLastError(); }
+#define P3_ABL(A) if (abl == A && nw == 8) { hipLaunchKernelGGL((attn_prefill32_kernel<8, 0, 8, A>), grid, dim3(512), 0, s, qkv, kv, seq_starts, start_pos, cache_indices, max_pages, b0, H, Hkv, nreq, nqb, out, nullptr); return hipGetLastError(); }
     P3_ABL(1) P3_ABL(2) P3_ABL(3) P3_ABL(7)
 #undef P3_ABL
 #endif

@@ -37,13 +37,15 @@ hipError_t launch_attn_decode(hipStream_t s, const uint16_t* qkv, const KvAddr& 
 hipError_t launch_attn_prefill(hipStream_t s, const uint16_t* qkv, const KvAddr& kv, int quant_bit,
                                const int64_t* seq_starts, const int64_t* start_pos, const int64_t* cache_indices,
                                int64_t max_pages, int64_t b0, int64_t B, int H, int Hkv, int D, int64_t max_seq_len,
-                               uint16_t* out);
+                               uint16_t* out, int64_t max_kv_len = 0, float* ws = nullptr, size_t ws_bytes = 0, int64_t row0 = 0,
+                               int64_t nrows = 0);  // max_kv_len .. nrows: optional, enable the split-KV form for short suffixes (k_attn_prefill32.hip)
 
 // ---- k_attn_prefill32.hip ---------------------------------------------------------------------
 // the same operation for head_dim 128 on the 32-row wave tile (mfma_f32_32x32x16_f16, 64-key tiles, one barrier per tile)
 hipError_t launch_attn_prefill32(hipStream_t s, const uint16_t* qkv, const KvAddr& kv, int quant_bit, const int64_t* seq_starts,
                                  const int64_t* start_pos, const int64_t* cache_indices, int64_t max_pages, int64_t b0, int64_t B,
-                                 int H, int Hkv, int D, int64_t max_seq_len, uint16_t* out);
+                                 int H, int Hkv, int D, int64_t max_seq_len, uint16_t* out, int64_t max_kv_len = 0, float* ws = nullptr,
+                                 size_t ws_bytes = 0, int64_t row0 = 0, int64_t nrows = 0);
 
 // ---- k_attn_decode_gqa.hip --------------------------------------------------------------------
 // grouped-query decode (4 <= H/Hkv <= 16): MFMA kernel, one block per (request, KV head[, split]); same workspace layout

@@ -1181,8 +1181,10 @@ static int layer_attention_part(pplhip_ctx* c, int rank, int l, const Chunk& k, 
     }
     if (k.bn > k.nd) {
         prof_begin(c, R, PPLHIP_PROF_ATTN_PREFILL, &ev);
+        // (decode requests own one token row each, so the prefill requests' rows are [t0 + nd, t0 + tn): the split-KV form for short suffixes)
         HIPCK(c, rank, launch_attn_prefill(s, R.qkv, kv, d.cache_quant_bit, R.d_seq, R.d_sp, R.d_ci, R.max_pages, k.b0 + k.nd,
-                                           k.b0 + k.bn, H, Hkv, D, R.max_seq_len, R.att));
+                                           k.b0 + k.bn, H, Hkv, D, R.max_seq_len, R.att, R.max_kv_len, R.attn_ws, R.attn_ws_bytes,
+                                           k.t0 + k.nd, k.tn - k.nd));
         prof_end(R, &ev);
     }
     prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
@@ -1700,7 +1702,8 @@ int pplhip_op_attention(void* stream, const void* qkv, const pplhip_kv_view* kv,
                                num_heads, kv->kv_heads, kv->head_dim, max_kv_len, split, 256, (float*)workspace, (uint16_t*)out);
     if (e == hipSuccess && B > nb)
         e = launch_attn_prefill(s, (const uint16_t*)qkv, a, kv->quant_bit, seq_starts, start_pos, cache_indices, max_pages, nb, B,
-                                num_heads, kv->kv_heads, kv->head_dim, max_seq_len, (uint16_t*)out);
+                                num_heads, kv->kv_heads, kv->head_dim, max_seq_len, (uint16_t*)out, max_kv_len, (float*)workspace,
+                                (size_t)workspace_bytes, nb, T - nb);
     return op_rc(e);
 }
 

@@ -381,6 +381,44 @@ def test_attention_long_prefill_and_cache_prefill(quant, seqlens, start, heads, 
     close_f16(got, want, rel=1e-3, abs_=1e-3 * vmax)   # observed (r02) <= 5.1e-4 |V|max
 
 
+@pytest.mark.parametrize("quant", [8, 0])
+@pytest.mark.parametrize("seqlens,start,heads,mode", [([16], [8176], (8, 1), 1), ([7, 16, 1], [2000, 5000, 4097], (4, 4), 0),
+                                                        ([32, 3], [1000, 1500], (2, 2), 1)])
+def test_attention_short_suffix_split_kv(quant, seqlens, start, heads, mode):
+    """cache-prefill of a few new tokens behind a long cached prefix (what a prefix-cache hit leaves to compute): with a workspace the
+    launcher splits the keys over several blocks per (request, head) and merges the partial rows -- against the oracle, and equal
+    (to fp16 rounding of the merge) to the unsplit kernel."""
+    m = load_pplhip()
+    H, Hkv = heads
+    D = 128
+    case = KvCase(m, H, Hkv, D, L=1, layer=0, quant=quant, layout=3, mode=mode, seqlens=seqlens, start_pos=start,
+                  seed=len(seqlens) + quant + H, page_size=16, decoding_batches=0)
+    rng = np.random.RandomState(23)
+    if quant:
+        case.cache[:] = rng.randint(-127, 128, size=case.cache.size).astype(np.int8)
+        case.scale[:] = f16(0.02 * (0.5 + rng.rand(case.scale.size)))
+    else:
+        case.cache[:] = f16(rng.randn(case.cache.size))
+    q32 = case.ref_write()
+    want = case.ref_attention(q32)
+    dq = dev(q32.astype(np.float16))
+    dcache, dscale = dev(case.cache), (dev(case.scale) if quant else None)
+    v = case.view(dcache, dscale)
+    ws = torch.zeros(case.T * H * 32 * (D + 2), dtype=torch.float32, device="cuda")
+    outs = []
+    for wsp, wsb in ((ws.data_ptr(), ws.numel() * 4), (None, 0)):
+        out = torch.zeros((case.T, H * D), dtype=torch.float16, device="cuda")
+        ck(m.lib().pplhip_op_attention(None, dq.data_ptr(), C.byref(v), dev(case.seq_starts).data_ptr(), dev(case.start_pos).data_ptr(),
+                                       dev(case.cache_idx).data_ptr(), case.max_pages, case.B, case.T, 0, case.max_seq_len,
+                                       case.max_kv_len, H, 1, wsp, wsb, out.data_ptr()))
+        outs.append(out.cpu().numpy().astype(np.float32))
+    assert float(ws.abs().max()) > 0, "the split-KV path did not run"
+    vmax = 3.0 if not quant else 0.03 * 127
+    close_f16(outs[0], want, rel=1e-3, abs_=1e-3 * vmax)
+    close_f16(outs[1], want, rel=1e-3, abs_=1e-3 * vmax)
+    close_f16(outs[0], outs[1], rel=2e-3, abs_=2e-4 * vmax)
+
+
 def test_sampler_greedy_and_topk():
     m = load_pplhip()
     rng = np.random.RandomState(11)
