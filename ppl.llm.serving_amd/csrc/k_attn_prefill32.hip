@@ -367,22 +367,23 @@ hipError_t launch_attn_prefill32(hipStream_t s, const uint16_t* qkv, const KvAdd
                                  int64_t row0, int64_t nrows) {
     if (D != P3_D || (quant_bit != 0 && quant_bit != 8)) return hipErrorInvalidValue;
     if (B <= b0 || max_seq_len <= 0) return hipSuccess;
-    // Short new suffixes behind long caches (every request of the launch has <= 32 new tokens -- a prefix-cache hit recomputes one page --
-    // and there are too few (request, head) blocks to fill the chip): split the keys over gridDim.y blocks and merge (flash-decoding form).
-    // row0 / nrows: the token rows of these requests (they are contiguous in the step); ws: nrows x H x splits x (D + 2) floats.
+    // Few new tokens behind long caches (a prefix-cache hit recomputes one page; a short follow-up turn): when the launch has too few
+    // (query block, request, head) blocks to fill the chip, the keys of each are split over gridDim.y blocks whose partial rows are merged
+    // (flash-decoding form).  row0 / nrows: the token rows of these requests (contiguous in the step); ws: nrows x H x splits x (D + 2) floats.
     static const int split_env = getenv("PPLHIP_P32_SPLIT") ? atoi(getenv("PPLHIP_P32_SPLIT")) : -1;  // 0: never; n > 1: force n
-    if (split_env != 0 && ws && nrows > 0 && max_seq_len <= 32 && (int64_t)(B - b0) * H < 256 && max_kv_len >= 1024) {
-        const int64_t blocks = (int64_t)(B - b0) * H, ntiles = (max_kv_len + P3_BN - 1) / P3_BN;
-        int64_t nsplit = (512 + blocks - 1) / blocks;
+    const int64_t nqb4 = (max_seq_len + 127) / 128, blocks4 = nqb4 * (B - b0) * H;
+    if (split_env != 0 && ws && nrows > 0 && max_seq_len < 1024 && blocks4 < 256 && max_kv_len >= 1024) {
+        const int64_t ntiles = (max_kv_len + P3_BN - 1) / P3_BN;
+        int64_t nsplit = (512 + blocks4 - 1) / blocks4;
         if (nsplit > ntiles / 4) nsplit = ntiles / 4;   // at least four 64-key tiles per split
         if (nsplit > 32) nsplit = 32;
         if (split_env > 1) nsplit = split_env;
         while (nsplit > 1 && (size_t)nrows * H * nsplit * (P3_D + 2) * sizeof(float) > ws_bytes) --nsplit;
         if (nsplit > 1) {
             const int nreq = (int)(B - b0);
-            dim3 grid((unsigned)((int64_t)nreq * H), (unsigned)nsplit);
+            dim3 grid((unsigned)blocks4, (unsigned)nsplit);
 #define P3_SPLIT(QB, MD) hipLaunchKernelGGL((attn_prefill32_kernel<QB, MD, 4, 0, 1>), grid, dim3(256), 0, s, qkv, kv, seq_starts, start_pos, \
-                                            cache_indices, max_pages, b0, H, Hkv, nreq, 1, out, ws)
+                                            cache_indices, max_pages, b0, H, Hkv, nreq, (int)nqb4, out, ws)
             if (quant_bit == 8) { if (kv.mode == 0) P3_SPLIT(8, 0); else P3_SPLIT(8, 1); }
             else { if (kv.mode == 0) P3_SPLIT(0, 0); else P3_SPLIT(0, 1); }
 #undef P3_SPLIT

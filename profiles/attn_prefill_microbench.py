@@ -31,7 +31,7 @@ v = m.KvView()
 v.cache, v.scale, v.max_tokens, v.num_layers, v.kv_heads, v.head_dim = cache.data_ptr(), scale.data_ptr(), N, L, HKV, D
 v.quant_bit, v.quant_group, v.layout, v.mode, v.page_size, v.layer = 8, 8, 3, mode, PG if mode else 0, 0
 # MB_WS=1: hand the operator a workspace (enables the split-KV form for short suffixes behind long caches)
-ws = torch.empty(R * S * H * 32 * (D + 2), device="cuda", dtype=torch.float32) if os.environ.get("MB_WS") and S <= 32 else None
+ws = torch.empty(R * S * H * min(32, max(2, 512 // max(1, ((S + 127) // 128) * R * H) + 1)) * (D + 2), device="cuda", dtype=torch.float32) if os.environ.get("MB_WS") and S < 1024 else None
 call = lambda: m.lib().pplhip_op_attention(None, qkv.data_ptr(), C.byref(v), seq.data_ptr(), sp.data_ptr(), ci.data_ptr(), mp, R, R * S, 0, S,
                                            P + S, H, 1, ws.data_ptr() if ws is not None else None, ws.numel() * 4 if ws is not None else 0,
                                            out.data_ptr())

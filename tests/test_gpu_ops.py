@@ -383,7 +383,8 @@ def test_attention_long_prefill_and_cache_prefill(quant, seqlens, start, heads, 
 
 @pytest.mark.parametrize("quant", [8, 0])
 @pytest.mark.parametrize("seqlens,start,heads,mode", [([16], [8176], (8, 1), 1), ([7, 16, 1], [2000, 5000, 4097], (4, 4), 0),
-                                                        ([32, 3], [1000, 1500], (2, 2), 1)])
+                                                        ([32, 3], [1000, 1500], (2, 2), 1),
+                                                        ([300, 129], [2500, 900], (4, 4), 1), ([600], [1800], (2, 2), 0)])  # several query blocks
 def test_attention_short_suffix_split_kv(quant, seqlens, start, heads, mode):
     """cache-prefill of a few new tokens behind a long cached prefix (what a prefix-cache hit leaves to compute): with a workspace the
     launcher splits the keys over several blocks per (request, head) and merges the partial rows -- against the oracle, and equal
@@ -405,7 +406,7 @@ def test_attention_short_suffix_split_kv(quant, seqlens, start, heads, mode):
     dcache, dscale = dev(case.cache), (dev(case.scale) if quant else None)
     v = case.view(dcache, dscale)
     ws = torch.zeros(case.T * H * 32 * (D + 2), dtype=torch.float32, device="cuda")
-    outs = []
+    outs = []  # (first with the workspace: split-KV; then without: one block per (query block, request, head))
     for wsp, wsb in ((ws.data_ptr(), ws.numel() * 4), (None, 0)):
         out = torch.zeros((case.T, H * D), dtype=torch.float16, device="cuda")
         ck(m.lib().pplhip_op_attention(None, dq.data_ptr(), C.byref(v), dev(case.seq_starts).data_ptr(), dev(case.start_pos).data_ptr(),
