@@ -286,6 +286,114 @@ __global__ __launch_bounds__(512) void gemm_i8_pc_kernel(const int8_t* __restric
     }
 }
 
+// 128 (m) x 384 (n) x 128 (k) block: the int8 form of gemm_w8_wide_kernel (k_gemm_wide.hip).  Twelve consumer waves as 6 (n) x 2 (m), wave
+// tile 64 x 64 like the waves of the kernel above, share ONE activation tile; four producer waves keep a two-stage ring of 64 KiB filled.
+// Two co-resident 128 x 128 blocks move 64 KiB per 1024 MFMA cycles and CU -- the whole 64 B / clk of the CU's vector-memory path --, this
+// block moves 64 KiB per 3072 (profiles/r03_gemm_experiments.md #16-17).  Taken when its tiles fill rounds of 256 one-per-CU blocks.
+constexpr int IW_BN = 384, IW_NC = 12, IW_NP = 4, IW_ST = 2;
+constexpr int IW_XB = I_BM * I_BK, IW_WB = IW_BN * I_BK;       // 16 KiB + 48 KiB per stage
+constexpr int IW_PP = (IW_XB + IW_WB) / 1024 / IW_NP;           // 16 one-KiB pieces per producer wave and tile (4 activation + 12 weight)
+template <int EPI>
+__global__ __launch_bounds__((IW_NC + IW_NP) * 64) void gemm_i8_wide_kernel(const int8_t* __restrict__ xq, const float* __restrict__ sx,
+                                                                             const int8_t* __restrict__ w, const uint16_t* __restrict__ scale,
+                                                                             int64_t M, int N, int K, void* __restrict__ yv, int64_t ldy,
+                                                                             int n_tiles, int m_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem_i8[];  // IW_ST x (X 16 KiB) then IW_ST x (W 48 KiB)
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int nt = xcd + 8 * (slot / m_tiles);
+    const int mt = slot % m_tiles;
+    if (nt >= n_tiles) return;
+    const int n0 = nt * IW_BN;
+    const int64_t m0 = (int64_t)mt * I_BM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ktiles = K / I_BK;
+
+    if (wave >= IW_NC) {
+        // producer pw: pieces P = pw + 4 j; j < 4: activation piece P (rows 8 P .. + 8), else weight piece P - 16 (rows 8 (P - 16) .. + 8);
+        // 128-byte rows, 16-byte chunks XOR-swizzled with (row >> 1) & 7 on the SOURCE side (the DMA writes LDS linearly)
+        const int pw = wave - IW_NC;
+        const int8_t* psrc[IW_PP];
+        uint32_t pdst[IW_PP];
+        const uint32_t xbase = lds_addr(smem_i8), wbase = xbase + IW_ST * IW_XB;
+#pragma unroll
+        for (int j = 0; j < IW_PP; ++j) {
+            const int P = pw + IW_NP * j;
+            const bool isx = j < IW_XB / 1024 / IW_NP;
+            const int Pl = isx ? P : P - IW_XB / 1024;
+            const int p = Pl * 64 + lane, row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
+            if (isx) {
+                int64_t m = m0 + row;
+                if (m >= M) m = M - 1;
+                psrc[j] = xq + m * K + c * 16;
+                pdst[j] = __builtin_amdgcn_readfirstlane(xbase + Pl * 1024);
+            } else {
+                int n = n0 + row;
+                if (n >= N) n = N - 1;
+                psrc[j] = w + (int64_t)n * K + c * 16;
+                pdst[j] = __builtin_amdgcn_readfirstlane(wbase + Pl * 1024);
+            }
+        }
+#define IW_PRODUCE(KT, STG)                                                                                                  \
+    do {                                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < IW_PP; ++j)                                                                    \
+            glds16(psrc[j] + (int64_t)(KT) * I_BK, pdst[j] + (STG) * (j < IW_XB / 1024 / IW_NP ? IW_XB : IW_WB));            \
+    } while (0)
+        IW_PRODUCE(0, 0);
+        for (int t = 0; t < ktiles; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // tile t is published; the other stage (read during iteration t - 1) is free
+            if (t + 1 < ktiles) IW_PRODUCE(t + 1, (t + 1) & 1);
+        }
+#undef IW_PRODUCE
+        return;
+    }
+
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int wn = wave % 6, wm = wave / 6;
+    i4v acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = i4v{0, 0, 0, 0};
+    for (int t = 0; t < ktiles; ++t) {
+        __syncthreads();
+        const char* xs = smem_i8 + (t & 1) * IW_XB;
+        const char* ws = smem_i8 + IW_ST * IW_XB + (t & 1) * IW_WB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            i4v a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wn * 64 + i * 16 + l15;
+                a[i] = *reinterpret_cast<const i4v*>(ws + row * I_BK + g_swz(row, ks * 4 + kq) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wm * 64 + j * 16 + l15;
+                b[j] = *reinterpret_cast<const i4v*>(xs + row * I_BK + g_swz(row, ks * 4 + kq) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t m = m0 + wm * 64 + j * 16 + l15;
+        if (m >= M) continue;
+        const float sxm = sx[m];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + kq * 4;
+            if (n >= N) continue;
+            const h4 sh = __builtin_bit_cast(h4, *reinterpret_cast<const uint2*>(scale + n));
+            store4_i8<EPI>(yv, ldy, m, n, acc[i][j], sxm, sh);
+        }
+    }
+}
+
 // Large M (steps that carry prefill): 256(n) x 256(m) x 64(k) tiles, 8 waves as 4 (n) x 2 (m), wave tile 64 x 128 = 4 x 8 MFMA tiles
 // (12 fragment reads and 4 LDS-DMA pieces per 32 MFMAs and wave, against 16 and 8 in the 128 x 128 kernels), 64-byte rows with the
 // w_swz chunk swizzle for both operands, ST-stage ring of 32 KiB, one barrier per tile, one block per CU.
@@ -520,6 +628,25 @@ hipError_t launch_linear_i8(hipStream_t s, const int8_t* xq, const float* sx, co
             if (epi == EPI_F32) L2(EPI_F32); else if (epi == EPI_F16) L2(EPI_F16); else L2(EPI_SWIGLU);
 #undef L2
             return hipGetLastError();
+        }
+        {   // 128 x 384 tiles when they fill rounds of 256 one-per-CU blocks (the rule of linear_w8_wide_waves, k_gemm_wide.hip)
+            static const int wide = getenv("PPLHIP_GEMM_I8_WIDE") ? atoi(getenv("PPLHIP_GEMM_I8_WIDE")) : 1;
+            if (wide && M >= 512 && N >= 8192 && linear_w8_wide_waves(M, N) == 12) {
+                const int ntw = (N + IW_BN - 1) / IW_BN, mtw = (int)((M + I_BM - 1) / I_BM);
+                const size_t ldsw = (size_t)IW_ST * (IW_XB + IW_WB);
+                static bool attr_w[64] = {false};
+                if (!attr_w[dev & 63]) {
+                    (void)hipFuncSetAttribute((const void*)gemm_i8_wide_kernel<EPI_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+                    (void)hipFuncSetAttribute((const void*)gemm_i8_wide_kernel<EPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+                    (void)hipFuncSetAttribute((const void*)gemm_i8_wide_kernel<EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+                    attr_w[dev & 63] = true;
+                }
+                dim3 gw((unsigned)((ntw + 7) / 8 * 8 * mtw));
+#define LW(E) hipLaunchKernelGGL((gemm_i8_wide_kernel<E>), gw, dim3((IW_NC + IW_NP) * 64), ldsw, s, xq, sx, w, scale, M, N, K, y, ldy, ntw, mtw)
+                if (epi == EPI_F32) LW(EPI_F32); else if (epi == EPI_F16) LW(EPI_F16); else LW(EPI_SWIGLU);
+#undef LW
+                return hipGetLastError();
+            }
         }
         static const int forced_pc = getenv("PPLHIP_GEMM_I8_PC") ? atoi(getenv("PPLHIP_GEMM_I8_PC")) : -1;
         const int pc = forced_pc >= 0 ? forced_pc : ((int64_t)n_tiles * m_tiles <= 256 ? 4 : 2);

@@ -100,7 +100,8 @@ def quantised_inputs(M, N, K, seed):
 # skinny (M <= 16), generic (K % 128 != 0 or M <= 32), tile kernel (ragged M and N edges), the configurations' layer shapes
 @pytest.mark.parametrize("M,N,K", [(1, 256, 4096), (7, 4096, 4096), (16, 12288, 4096), (16, 22016, 1376), (33, 512, 1376),
                                    (24, 512, 256), (33, 512, 256), (200, 1000, 512), (129, 132, 128), (1024, 4096, 4096),
-                                   (1024, 4096, 11008), (1024, 5120, 6912), (300, 1280, 8192)])
+                                   (1024, 4096, 11008), (1024, 5120, 6912), (300, 1280, 8192),
+                                   (1024, 12288, 512), (1000, 12000, 384), (1024, 22016, 128)])   # the 128 x 384 producer / consumer kernel
 def test_linear_i8_bit_exact(M, N, K):
     m = load_pplhip()
     xs, xq, sx, w, scale = quantised_inputs(M, N, K, M + N + K)
@@ -115,7 +116,7 @@ def test_linear_i8_bit_exact(M, N, K):
         assert (got == want).all(), (np.abs(got - want).max(), int((got != want).sum()))
 
 
-@pytest.mark.parametrize("M,inter,K", [(5, 688, 512), (200, 1376, 512), (40, 176, 256)])
+@pytest.mark.parametrize("M,inter,K", [(5, 688, 512), (200, 1376, 512), (40, 176, 256), (1000, 6000, 256)])  # last: 128 x 384 kernel
 def test_linear_i8_swiglu(M, inter, K):
     m = load_pplhip()
     N = 2 * inter
