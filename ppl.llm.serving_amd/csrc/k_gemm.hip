@@ -463,6 +463,19 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
     if (wq_bit == 0 && K % 8) return hipErrorInvalidValue;
     if (wq_bit == 8 && K % 16) return hipErrorInvalidValue;
     if (wq_bit == 4 && (K % 32 || group % 32 || K % group)) return hipErrorInvalidValue;
+    // A few rows above a multiple of 1024 (a saturated continuous-batching step: 1024 decode rows + the prompt chunk of a newly admitted
+    // request) would add a ninth / seventeenth 128-row tile to every column block -- a whole extra round of tiles for a few rows (7B layer
+    // GEMMs at M = 1040: 555 us against 414 us at M = 1024).  The rows up to the multiple go through the shapes that fit, the rest as a
+    // second, small launch.
+    static const int msplit = getenv("PPLHIP_GEMM_MSPLIT") ? atoi(getenv("PPLHIP_GEMM_MSPLIT")) : 256;  // largest rest that is split off (0: never); measured: rest 16 / 76 / 128 / 256 -13 / -10 / -11 / -5 %, 384 equal
+    if (msplit && M > 1024 && M < 4096 && (M & 1023) != 0 && (M & 1023) <= msplit) {
+        const int64_t m_main = M & ~(int64_t)1023, m_rest = M - m_main;
+        const size_t yelt = out_fp32 ? 4 : 2;
+        hipError_t e = launch_linear(s, x, w, scale, wq_bit, group, m_main, N, K, y, ldy, out_fp32, ws, ws_bytes, swiglu);
+        if (e != hipSuccess) return e;
+        return launch_linear(s, x + m_main * K, w, scale, wq_bit, group, m_rest, N, K, (char*)y + (size_t)m_main * ldy * yelt, ldy, out_fp32, ws,
+                             ws_bytes, swiglu);
+    }
     static const bool no_skinny = getenv("PPLHIP_GEMM_NOSKINNY") != nullptr, force_generic = getenv("PPLHIP_GEMM_GENERIC") != nullptr;
     // the skinny kernel up to 3 rows; from 4 rows the half-height tile kernel (64 activation rows, split-K) is faster: 7B decode step at batch
     // 4 / 8 / 12 / 16 3.64 / 3.90 / 4.40 / 4.74 -> 3.56 / 3.73 / 3.81 / 4.18 ms (profiles/small_batch_latency.py); PPLHIP_GEMV_MAX_M overrides

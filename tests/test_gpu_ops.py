@@ -88,6 +88,7 @@ def test_rmsnorm(hidden, skip):
 @pytest.mark.parametrize("M,N,K", [(1, 128, 128), (5, 384, 256), (130, 320, 128), (64, 512, 1376), (257, 1024, 4096),
                                    (33, 1024, 704), (2100, 1284, 512), (100, 384, 4096), (200, 260, 2048), (1024, 1536, 1024),
                                    (4100, 1092, 256),    # M >= 4096: the 256 x 256 tile kernel (prefill steps)
+                                   (1040, 1284, 128), (2148, 516, 64),   # a few rows above a multiple of 1024: two launches (main part + rest)
                                    (1000, 12000, 192), (1024, 12288, 64),  # W8: the 128 x 384 producer / consumer kernel (ragged edges; one K tile < ring depth)
                                    (4608, 5120, 128), (8192, 2304, 64),   # its super-tile block order: 18 x 20 tiles (3 x 3 super-tiles), 32 x 9 (4 x 2, padded share)
                                    # per-rank shapes of BASELINE configs 3 / 4: 13B/TP2 wqkv and w2, 70B/TP8 wqkv, wo-like and w2
@@ -483,7 +484,7 @@ def test_sampler_pure_top_p_and_clamped_top_k(top_k, top_p):
 
 
 @pytest.mark.parametrize("wq", [0, 8, 4])
-@pytest.mark.parametrize("M,inter,K", [(3, 64, 128), (40, 192, 256), (300, 1376, 512), (1000, 6000, 128)])  # last: W8 -> 128 x 384 kernel
+@pytest.mark.parametrize("M,inter,K", [(3, 64, 128), (40, 192, 256), (300, 1376, 512), (1000, 6000, 128), (1030, 640, 128)])  # W8: 128 x 384 kernel; two launches
 def test_linear_swiglu_fused(wq, M, inter, K):
     """K3 + K10 fused: the GEMM over row-interleaved (gate_i, up_i) weights writes silu(gate) * up directly."""
     m = load_pplhip()
