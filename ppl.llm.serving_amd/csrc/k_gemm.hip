@@ -468,7 +468,7 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
     // GEMMs at M = 1040: 555 us against 414 us at M = 1024).  The rows up to the multiple go through the shapes that fit, the rest as a
     // second, small launch.
     static const int msplit = getenv("PPLHIP_GEMM_MSPLIT") ? atoi(getenv("PPLHIP_GEMM_MSPLIT")) : 256;  // largest rest that is split off (0: never); measured: rest 16 / 76 / 128 / 256 -13 / -10 / -11 / -5 %, 384 equal
-    if (msplit && M > 1024 && M < 4096 && (M & 1023) != 0 && (M & 1023) <= msplit) {
+    if (msplit && M > 1024 && M < 3584 && (M & 1023) != 0 && (M & 1023) <= msplit) {
         const int64_t m_main = M & ~(int64_t)1023, m_rest = M - m_main;
         const size_t yelt = out_fp32 ? 4 : 2;
         hipError_t e = launch_linear(s, x, w, scale, wq_bit, group, m_main, N, K, y, ldy, out_fp32, ws, ws_bytes, swiglu);
@@ -500,7 +500,7 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
     const int m_tiles = (int)((M + G_BM - 1) / G_BM);
     const int n_tiles_pad = (n_tiles + 7) / 8 * 8;
     dim3 grid((unsigned)(n_tiles_pad * m_tiles)), block(256);
-    static const int min_m256 = getenv("PPLHIP_GEMM_256_MIN_M") ? atoi(getenv("PPLHIP_GEMM_256_MIN_M")) : 4096;  // measured: only pays at M >= 4096
+    static const int min_m256 = getenv("PPLHIP_GEMM_256_MIN_M") ? atoi(getenv("PPLHIP_GEMM_256_MIN_M")) : 3584;  // measured (7B layer): M = 3584 1435 vs 1501 us, 3072 1277 vs 1264, 2560 equal, 2048 941 vs 851
     if (wq_bit == 8 && K % G_BK == 0 && M >= min_m256 && N >= 1024 && !force_generic) {
         const int nt2 = (N + H_BN - 1) / H_BN, mt2 = (int)((M + H_BM - 1) / H_BM);
         const size_t lds = (size_t)H_ST * (H_BM * G_BK * 2 + H_BN * G_BK);
