@@ -50,7 +50,9 @@ static inline f16 f2h(float f) { return _cvtss_sh(f, _MM_FROUND_TO_NEAREST_INT |
  *   bit 2  REF_MODE_ALT_ORDER dot products in a different, equally valid fp32 summation order: oracle(mode 4) vs oracle(mode 0)
  *                             measures how far two correct fp16 implementations of this specification drift apart
  *                             (the noise floor the device tolerances are derived from, tests/test_gpu_fulldepth.py) */
-enum { REF_MODE_FP32_ACT = 1, REF_MODE_F64_ACC = 2, REF_MODE_ALT_ORDER = 4 };
+/*   bit 3  REF_MODE_ALT_ORDER2 a third valid order (one 8-lane accumulator over 8-element steps, lanes summed as a tree): with
+ *                             three orders the noise floor is the largest of three pairwise distances instead of one sample */
+enum { REF_MODE_FP32_ACT = 1, REF_MODE_F64_ACC = 2, REF_MODE_ALT_ORDER = 4, REF_MODE_ALT_ORDER2 = 8 };
 static int g_mode = 0;
 static inline float rh(float f) { return (g_mode & REF_MODE_FP32_ACT) ? f : h2f(f2h(f)); } /* round through fp16 */
 
@@ -376,10 +378,14 @@ REF_API void ref_embedding(const int64_t* token_ids, const f16* table, int64_t T
 /* K2 (Skip)RMSNorm: s = x (+ skip); residual_out = fp16(s); y = fp16(fp32(residual) * rsqrt(mean(r^2)+eps) * w) */
 REF_API void ref_rmsnorm(const float* x, const float* skip, const f16* w, float eps, int64_t T, int hidden, float* out,
                          float* residual_out) {
-#pragma omp parallel for
+#pragma omp parallel
+    {
+    /* (one scratch row per thread: an alloca inside the loop is only released when the outlined function returns -- 16 KB per
+     * token row overflowed the thread stacks from ~4000 rows per step, found by the 6144-token step of config 5, round 4) */
+    float* tmp = (float*)malloc(sizeof(float) * hidden);
+#pragma omp for
     for (int64_t t = 0; t < T; ++t) {
         const float* xr = x + t * hidden;
-        float* tmp = (float*)alloca(sizeof(float) * hidden);
         double ss = 0;
         for (int i = 0; i < hidden; ++i) {
             float s = xr[i];
@@ -390,6 +396,8 @@ REF_API void ref_rmsnorm(const float* x, const float* skip, const f16* w, float 
         if (residual_out) memcpy(residual_out + t * hidden, tmp, sizeof(float) * hidden);
         const float inv = 1.0f / sqrtf((float)(ss / hidden) + eps);
         for (int i = 0; i < hidden; ++i) out[t * hidden + i] = rh(tmp[i] * inv * h2f(w[i]));
+    }
+    free(tmp);
     }
 }
 
@@ -414,6 +422,15 @@ static inline float dot_f32(const float* a, const float* b, int n) {
         float t[8]; _mm256_storeu_ps(t, _mm256_add_ps(c0, c1));
         float s = 0;
         for (int i = 0; i < 8; ++i) s += t[i];
+        for (; k < n; ++k) s += a[k] * b[k];
+        return s;
+    }
+    if (g_mode & REF_MODE_ALT_ORDER2) { /* one 8-lane accumulator over 8-element steps, lanes summed pairwise */
+        __m256 c0 = _mm256_setzero_ps();
+        int k = 0;
+        for (; k + 8 <= n; k += 8) c0 = _mm256_fmadd_ps(_mm256_loadu_ps(a + k), _mm256_loadu_ps(b + k), c0);
+        float t[8]; _mm256_storeu_ps(t, c0);
+        float s = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
         for (; k < n; ++k) s += a[k] * b[k];
         return s;
     }
@@ -443,42 +460,52 @@ static void linear_fwd_a8(const ref_linear* l, const float* x, int64_t M, float*
 REF_API void ref_linear_fwd(const ref_linear* l, const float* x, int64_t M, float* y, int out_fp32) {
     const int N = l->N, K = l->K;
     if (l->qbit == 8 && l->a8) { linear_fwd_a8(l, x, M, y, out_fp32); return; }
+    /* NB weight rows are dequantised at a time and every activation row is multiplied against all of them while it sits in L1: the
+     * activations stream through the caches N / NB times instead of N times (round 4: the 6144-token steps of config 5 were
+     * memory-bound at ~16 GFLOP/s).  Every dot product is still ONE dot_f32 call: the summation order, hence every bit, is unchanged. */
+    enum { NB = 8 };
 #pragma omp parallel
     {
-        float* wrow = (float*)malloc(sizeof(float) * K);
+        float* wblk = (float*)malloc(sizeof(float) * K * NB);
 #pragma omp for schedule(static)
-        for (int n = 0; n < N; ++n) {
-            if (l->qbit == 0) {
-                const f16* w = l->w16 + (size_t)n * K;
-                int k = 0;
-                for (; k + 8 <= K; k += 8) _mm256_storeu_ps(wrow + k, _mm256_cvtph_ps(_mm_loadu_si128((const __m128i*)(w + k))));
-                for (; k < K; ++k) wrow[k] = h2f(w[k]);
-            } else if (l->qbit == 8) {
-                const int8_t* w = l->w8 + (size_t)n * K;
-                int k = 0;
-                for (; k + 8 <= K; k += 8)
-                    _mm256_storeu_ps(wrow + k, _mm256_cvtepi32_ps(_mm256_cvtepi8_epi32(_mm_loadl_epi64((const __m128i*)(w + k)))));
-                for (; k < K; ++k) wrow[k] = (float)w[k];
-            } else {
-                /* W4A16: the dequantised weight IS an fp16 number, w = fp16((nibble - 8) * scale[n, k / group]) (the product is
-                 * exact in fp32, so this is one rounding) -- what a W4A16 kernel feeds its fp16 matrix unit; then an fp32 dot */
-                const uint8_t* w = l->w4 + (size_t)n * K / 2;
-                const int G = K / l->group;
-                for (int k = 0; k < K; k += 2) {
-                    const float sc = h2f(l->scale[(size_t)n * G + k / l->group]);
-                    wrow[k] = rh((float)((int)(w[k / 2] & 15) - 8) * sc);
-                    wrow[k + 1] = rh((float)((int)(w[k / 2] >> 4) - 8) * sc);
+        for (int n0 = 0; n0 < N; n0 += NB) {
+            const int nb = N - n0 < NB ? N - n0 : NB;
+            for (int j = 0; j < nb; ++j) {
+                const int n = n0 + j;
+                float* wrow = wblk + (size_t)j * K;
+                if (l->qbit == 0) {
+                    const f16* w = l->w16 + (size_t)n * K;
+                    int k = 0;
+                    for (; k + 8 <= K; k += 8) _mm256_storeu_ps(wrow + k, _mm256_cvtph_ps(_mm_loadu_si128((const __m128i*)(w + k))));
+                    for (; k < K; ++k) wrow[k] = h2f(w[k]);
+                } else if (l->qbit == 8) {
+                    const int8_t* w = l->w8 + (size_t)n * K;
+                    int k = 0;
+                    for (; k + 8 <= K; k += 8)
+                        _mm256_storeu_ps(wrow + k, _mm256_cvtepi32_ps(_mm256_cvtepi8_epi32(_mm_loadl_epi64((const __m128i*)(w + k)))));
+                    for (; k < K; ++k) wrow[k] = (float)w[k];
+                } else {
+                    /* W4A16: the dequantised weight IS an fp16 number, w = fp16((nibble - 8) * scale[n, k / group]) (the product is
+                     * exact in fp32, so this is one rounding) -- what a W4A16 kernel feeds its fp16 matrix unit; then an fp32 dot */
+                    const uint8_t* w = l->w4 + (size_t)n * K / 2;
+                    const int G = K / l->group;
+                    for (int k = 0; k < K; k += 2) {
+                        const float sc = h2f(l->scale[(size_t)n * G + k / l->group]);
+                        wrow[k] = rh((float)((int)(w[k / 2] & 15) - 8) * sc);
+                        wrow[k + 1] = rh((float)((int)(w[k / 2] >> 4) - 8) * sc);
+                    }
                 }
             }
             for (int64_t m = 0; m < M; ++m) {
                 const float* xr = x + m * K;
-                float acc;
-                acc = dot_f32(xr, wrow, K);
-                if (l->qbit == 8) acc *= h2f(l->scale[n]);
-                y[m * N + n] = out_fp32 ? acc : rh(acc);
+                for (int j = 0; j < nb; ++j) {
+                    float acc = dot_f32(xr, wblk + (size_t)j * K, K);
+                    if (l->qbit == 8) acc *= h2f(l->scale[n0 + j]);
+                    y[m * N + n0 + j] = out_fp32 ? acc : rh(acc);
+                }
             }
         }
-        free(wrow);
+        free(wblk);
     }
 }
 
@@ -658,7 +685,11 @@ REF_API void ref_attention(const float* qkv, const ref_model_desc* d, int H, int
                     }
                     else {
                         const int64_t sbase = layer * ss.sL + 0 * ss.sKV + hk * ss.sH + slot * ss.sN;
-                        for (int i = 0; i < D; ++i) vec[i] = (float)((const int8_t*)kv_cache)[base + i] * h2f(kv_scale[sbase + i / g]);
+                        const int8_t* kq = (const int8_t*)kv_cache + base;   /* (group-blocked: same products, vectorisable) */
+                        for (int gi = 0; gi < D / g; ++gi) {
+                            const float s1 = h2f(kv_scale[sbase + gi]);
+                            for (int i = gi * g; i < (gi + 1) * g; ++i) vec[i] = (float)kq[i] * s1;
+                        }
                     }
                     sc[j] = dot_f32(q, vec, D) * sm;
                     mx = fmaxf(mx, sc[j]);
@@ -675,8 +706,12 @@ REF_API void ref_attention(const float* qkv, const ref_model_desc* d, int H, int
                     }
                     else {
                         const int64_t sbase = layer * ss.sL + 1 * ss.sKV + hk * ss.sH + slot * ss.sN;
-                        for (int i = 0; i < D; ++i)
-                            acc[i] += (double)p * ((float)((const int8_t*)kv_cache)[base + i] * h2f(kv_scale[sbase + i / g]));
+                        const int8_t* vq = (const int8_t*)kv_cache + base;
+                        const double pd = (double)p;
+                        for (int gi = 0; gi < D / g; ++gi) {
+                            const float s1 = h2f(kv_scale[sbase + gi]);
+                            for (int i = gi * g; i < (gi + 1) * g; ++i) acc[i] += pd * (double)((float)vq[i] * s1);
+                        }
                     }
                 }
                 for (int i = 0; i < D; ++i) out[t * (int64_t)H * D + (int64_t)hq * D + i] = rh((float)(acc[i] / den));

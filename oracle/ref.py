@@ -128,7 +128,7 @@ def lib():
     return _LIB
 
 
-MODE_FP16, MODE_FP32_ACT, MODE_F64_ACC, MODE_ALT_ORDER = 0, 1, 2, 4
+MODE_FP16, MODE_FP32_ACT, MODE_F64_ACC, MODE_ALT_ORDER, MODE_ALT_ORDER2 = 0, 1, 2, 4, 8
 
 
 class mode:

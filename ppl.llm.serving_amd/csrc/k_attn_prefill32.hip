@@ -35,7 +35,8 @@ __device__ __forceinline__ uint2 p3_v_frag(const uint16_t* sub, int r0, int l15)
 __device__ __forceinline__ int crow(int i, int hi) { return (i & 3) + 8 * (i >> 2) + 4 * hi; }
 
 // SPLIT: the block handles the KV tiles of split blockIdx.y of gridDim.y only and writes unnormalised partial rows (O, m, l) to `ws`
-// ([token row][head][split][D + 2] floats, the layout of the decode kernels); attn_prefill32_reduce_kernel merges them.  For short new
+// ([token row - ws_row0][head][split][D + 2] floats, the layout of the decode kernels: the workspace holds the launch's own rows only,
+// whatever decode rows or earlier chunks precede them in the step); attn_prefill32_reduce_kernel merges them.  For short new
 // suffixes behind a long cached prefix (a prefix-cache hit recomputes one page): a request is otherwise H blocks walking thousands of keys.
 template <int QBIT, int MODE, int NW, int ABL = 0, int SPLIT = 0>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_prefill32_kernel(const uint16_t* __restrict__ qkv, KvAddr kv,
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                                                                     const int64_t* __restrict__ start_pos,
                                                                     const int64_t* __restrict__ cache_indices, int64_t max_pages,
                                                                     int64_t b0, int H, int Hkv, int nreq, int nqb, uint16_t* __restrict__ out,
-                                                                    float* __restrict__ ws) {
+                                                                    float* __restrict__ ws, int64_t ws_row0) {
     constexpr int D = P3_D;
     constexpr int P3_BM = NW * 32, P3_THREADS = NW * 64;  // NW waves x 32 query rows share the staged K / V tiles
     constexpr int ELT = QBIT == 8 ? 1 : 2;
@@ -229,7 +230,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 if (ks + 2 < KSTEPS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
             // ---- online softmax of query l31; this lane holds keys key0 + 32 kb + crow(i, hi).  The running maximum m stays in
-            // RAW score units; scale x log2(e) is folded into the exponent's fma: p = 2^(s c - m c) ----------------------------------
+            // RAW score units; scale x log2(e) is folded into the exponent's fma: p = 2^(s c - m c).  Masked scores are -inf while m
+            // starts FINITE (-1e30): a row whose first tile of a split is wholly masked keeps m, gets alpha = 2^0 and p = 2^(-inf) = 0
+            // exactly, whatever the rounding of m c (with a -1e30 mask p was 2^(rounding residual)) ------------------------
             if (key0 + P3_BN - 1 > sp + wrow0) {  // wave-uniform: some key of the tile may exceed a row's position
                 const int64_t d = qpos - key0;
                 const int qrel = d < 0 ? -1 : (d > 2 * P3_BN ? 2 * P3_BN : (int)d);  // keys of the tile with index <= qrel are visible
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
-                        sacc[kb][i] = (32 * kb + crow(i, hi) <= qrel) ? sacc[kb][i] : -1e30f;
+                        sacc[kb][i] = (32 * kb + crow(i, hi) <= qrel) ? sacc[kb][i] : -INFINITY;
             }
             float mx0 = sacc[0][0], mx1 = sacc[1][0];
 #pragma unroll
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float x = __builtin_fmaf(sacc[kb][i], sm_scale2, nmc);  // masked scores: 2^(-1e29) = 0
+                    const float x = __builtin_fmaf(sacc[kb][i], sm_scale2, nmc);  // masked scores: 2^(-inf) = 0
                     const float e = (ABL & 4) ? x : __builtin_amdgcn_exp2f(x);
                     sacc[kb][i] = e;
                     rs4[i & 3] += e;
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             const float lr = __shfl(l, r, 64), mr = __shfl(m, r, 64);
             const int64_t qrow_i = wrow0 + r;
             if (qrow_i < seqlen) {
-                float* wrow = ws + (((seq_starts[b] + qrow_i) * H + hq) * (int64_t)gridDim.y + blockIdx.y) * (D + 2);
+                float* wrow = ws + (((seq_starts[b] + qrow_i - ws_row0) * H + hq) * (int64_t)gridDim.y + blockIdx.y) * (D + 2);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) wrow[c * 32 + l31] = o[c][i];
                 if (l31 == 0) { wrow[D] = mr * to_nat; wrow[D + 1] = lr; }
@@ -339,8 +342,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 // merges the splits of token rows [row0, row0 + gridDim.x / H): one block per (row, head), one thread per channel
 __global__ void attn_prefill32_reduce_kernel(const float* __restrict__ ws, int nsplit, int64_t row0, int H, uint16_t* __restrict__ out) {
     constexpr int D = P3_D;
-    const int64_t bh = row0 * H + blockIdx.x;
-    const float* w = ws + bh * (int64_t)nsplit * (D + 2);
+    const int64_t bh = row0 * H + blockIdx.x;  // absolute (row, head) of the output; the workspace is relative to row0
+    const float* w = ws + (int64_t)blockIdx.x * nsplit * (D + 2);
     const int d = threadIdx.x;
     float mm = -1e30f;
     for (int sp = 0; sp < nsplit; ++sp) mm = fmaxf(mm, w[sp * (D + 2) + D]);
@@ -383,7 +386,7 @@ hipError_t launch_attn_prefill32(hipStream_t s, const uint16_t* qkv, const KvAdd
             const int nreq = (int)(B - b0);
             dim3 grid((unsigned)blocks4, (unsigned)nsplit);
 #define P3_SPLIT(QB, MD) hipLaunchKernelGGL((attn_prefill32_kernel<QB, MD, 4, 0, 1>), grid, dim3(256), 0, s, qkv, kv, seq_starts, start_pos, \
-                                            cache_indices, max_pages, b0, H, Hkv, nreq, (int)nqb4, out, ws)
+                                            cache_indices, max_pages, b0, H, Hkv, nreq, (int)nqb4, out, ws, row0)
             if (quant_bit == 8) { if (kv.mode == 0) P3_SPLIT(8, 0); else P3_SPLIT(8, 1); }
             else { if (kv.mode == 0) P3_SPLIT(0, 0); else P3_SPLIT(0, 1); }
 #undef P3_SPLIT
@@ -401,10 +404,10 @@ hipError_t launch_attn_prefill32(hipStream_t s, const uint16_t* qkv, const KvAdd
     const int nqb = (int)((max_seq_len + bm - 1) / bm), nreq = (int)(B - b0);
     dim3 grid((unsigned)((int64_t)nqb * nreq * H));
 #define P3_LAUNCH(QB, MD, NW_) hipLaunchKernelGGL((attn_prefill32_kernel<QB, MD, NW_>), grid, dim3(NW_ * 64), 0, s, qkv, kv, seq_starts, start_pos, \
-                                                  cache_indices, max_pages, b0, H, Hkv, nreq, nqb, out, nullptr)
+                                                  cache_indices, max_pages, b0, H, Hkv, nreq, nqb, out, nullptr, 0)
 #ifdef P3_ABLATE_BUILD  // diagnosis build (profiles/r03_prefill_attention_ablation.md): wrong results, same instruction stream otherwise
     static const int abl = getenv("PPLHIP_P32_ABLATE") ? atoi(getenv("PPLHIP_P32_ABLATE")) : 0;
-#define P3_ABL(A) if (abl == A && nw == 8) { hipLaunchKernelGGL((attn_prefill32_kernel<8, 0, 8, A>), grid, dim3(512), 0, s, qkv, kv, seq_starts, start_pos, cache_indices, max_pages, b0, H, Hkv, nreq, nqb, out, nullptr); return hipGetLastError(); }
+#define P3_ABL(A) if (abl == A && nw == 8) { hipLaunchKernelGGL((attn_prefill32_kernel<8, 0, 8, A>), grid, dim3(512), 0, s, qkv, kv, seq_starts, start_pos, cache_indices, max_pages, b0, H, Hkv, nreq, nqb, out, nullptr, 0); return hipGetLastError(); }
     P3_ABL(1) P3_ABL(2) P3_ABL(3) P3_ABL(7)
 #undef P3_ABL
 #endif

@@ -42,20 +42,40 @@ __device__ __forceinline__ u64 ld_sys(const u64* p) { return __hip_atomic_load(p
 
 // 16-byte system-scope accesses (global_load/store_dwordx4 ... sc0 sc1): the same cache-bypass bits the 8-byte atomics above
 // compile to, at the widest access the memory pipeline has -- half the instructions per byte pulled over a link.  Issued from
-// inline asm (HIP has no 16-byte atomic): the compiler does not count them, so every batch of loads is followed by wait16(),
-// which ties the loaded registers to an s_waitcnt vmcnt(0).
+// inline asm (HIP has no 16-byte atomic): the compiler does not count them, so a batch of loads and its s_waitcnt vmcnt(0) are one
+// asm statement (ld_sys16_batch).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ u32x4 ld_sys16(const void* p) {
-    u32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
 __device__ __forceinline__ void st_sys16(void* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+// A batch of N 16-byte system-scope loads AND their s_waitcnt in ONE asm statement (early-clobber outputs): the compiler never sees a
+// destination register between its load and the wait, so no copy / phi / spill of it can read stale data (the loads used
+// to be separate statements tied to a later wait only through register constraints).  Every load is unconditional -- callers clamp the
+// address of a lane that has nothing to fetch to a valid one and ignore the result.
+#define LD1 "global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off sc0 sc1\n\t"
+__device__ __forceinline__ void ld_sys16x2(u32x4& a, u32x4& b, const void* pa, const void* pb) {
+    asm volatile(LD1 "s_waitcnt vmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(pa), "v"(pb) : "memory");
+}
+#undef LD1
+__device__ __forceinline__ void ld_sys16x4(u32x4& a, u32x4& b, u32x4& c, u32x4& d, const void* pa, const void* pb, const void* pc, const void* pd) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc0 sc1\n\tglobal_load_dwordx4 %3, %7, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(pa), "v"(pb), "v"(pc), "v"(pd) : "memory");
+}
 template <int N>
-__device__ __forceinline__ void wait16(u32x4 (&v)[N]) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));  // uses of v[i] stay below the wait
+__device__ __forceinline__ void ld_sys16_batch(u32x4 (&v)[N], const void* (&p)[N]) {
+    static_assert(N == 2 || N == 4 || N == 8, "rank counts 2 / 4 / 8 (the generic kernel pads to 8)");
+    if constexpr (N == 2) {
+        ld_sys16x2(v[0], v[1], p[0], p[1]);
+    } else if constexpr (N == 4) {
+        ld_sys16x4(v[0], v[1], v[2], v[3], p[0], p[1], p[2], p[3]);
+    } else {
+        asm volatile("global_load_dwordx4 %0, %8, off sc0 sc1\n\tglobal_load_dwordx4 %1, %9, off sc0 sc1\n\t"
+                     "global_load_dwordx4 %2, %10, off sc0 sc1\n\tglobal_load_dwordx4 %3, %11, off sc0 sc1\n\t"
+                     "global_load_dwordx4 %4, %12, off sc0 sc1\n\tglobal_load_dwordx4 %5, %13, off sc0 sc1\n\t"
+                     "global_load_dwordx4 %6, %14, off sc0 sc1\n\tglobal_load_dwordx4 %7, %15, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                     : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+                     : "memory");
+    }
 }
 
 // block b of this rank <-> block b of every peer.  END: the block's data stores must have landed before the flag goes out.
@@ -108,10 +128,10 @@ __global__ __launch_bounds__(512) void p2p_allreduce_kernel(P2pPeers peers, int 
         char* mine = peers.base[me] + scratch_off;
         for (int64_t g = lo + tid; g < hi; g += nthr) {
             u32x4 v[MAXN];
+            const void* src[MAXN];
 #pragma unroll
-            for (int r = 0; r < MAXN; ++r)
-                v[r] = r < n ? ld_sys16(peers.base[r] + data_off + g * 16) : u32x4{0, 0, 0, 0};
-            wait16(v);
+            for (int r = 0; r < MAXN; ++r) src[r] = peers.base[r < n ? r : me] + data_off + g * 16;  // (a rank slot past n re-reads my own copy)
+            ld_sys16_batch<MAXN>(v, src);
             float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < MAXN; ++r)
@@ -125,10 +145,11 @@ __global__ __launch_bounds__(512) void p2p_allreduce_kernel(P2pPeers peers, int 
         u32x4* out = reinterpret_cast<u32x4*>(peers.base[me] + data_off);
         for (int64_t g = tid; g < per; g += nthr) {
             u32x4 v[MAXN];
+            const void* src[MAXN];
 #pragma unroll
-            for (int r = 0; r < MAXN; ++r)
-                v[r] = (r < n && per * r + g < granules) ? ld_sys16(peers.base[r] + scratch_off + g * 16) : u32x4{0, 0, 0, 0};
-            wait16(v);
+            for (int r = 0; r < MAXN; ++r)  // (granules past the end of the last slice: scratch holds room for `per` granules on every rank; not stored)
+                src[r] = peers.base[r < n ? r : me] + scratch_off + g * 16;
+            ld_sys16_batch<MAXN>(v, src);
 #pragma unroll
             for (int r = 0; r < MAXN; ++r)
                 if (r < n && per * r + g < granules) out[per * r + g] = v[r];
@@ -148,9 +169,10 @@ __global__ __launch_bounds__(512) void p2p_allgather_kernel(P2pPeers peers, int 
         const int64_t row = g / row_granules, col = g - row * row_granules;
         if (GB == 16) {
             u32x4 v[P2P_MAX_RANKS];
+            const void* src[P2P_MAX_RANKS];
 #pragma unroll
-            for (int r = 0; r < P2P_MAX_RANKS; ++r) v[r] = r < n ? ld_sys16(peers.base[r] + src_off + g * 16) : u32x4{0, 0, 0, 0};
-            wait16(v);
+            for (int r = 0; r < P2P_MAX_RANKS; ++r) src[r] = peers.base[r < n ? r : me] + src_off + g * 16;
+            ld_sys16_batch<P2P_MAX_RANKS>(v, src);
 #pragma unroll
             for (int r = 0; r < P2P_MAX_RANKS; ++r)
                 if (r < n) reinterpret_cast<u32x4*>(dst)[row * dst_row_granules + (int64_t)r * row_granules + col] = v[r];

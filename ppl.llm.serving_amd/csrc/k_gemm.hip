@@ -480,7 +480,8 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
     // the skinny kernel up to 3 rows; from 4 rows the half-height tile kernel (64 activation rows, split-K) is faster: 7B decode step at batch
     // 4 / 8 / 12 / 16 3.64 / 3.90 / 4.40 / 4.74 -> 3.56 / 3.73 / 3.81 / 4.18 ms (profiles/small_batch_latency.py); PPLHIP_GEMV_MAX_M overrides
     static const int gemv_max_m = getenv("PPLHIP_GEMV_MAX_M") ? atoi(getenv("PPLHIP_GEMV_MAX_M")) : 3;
-    if (M <= gemv_max_m && M <= 16 && !no_skinny) {
+    // (without a split-K workspace the half-height tiles would run as N / 128 unsplit blocks: the skinny kernel keeps its 16 rows there)
+    if (M <= (ws && ws_bytes ? gemv_max_m : 16) && M <= 16 && !no_skinny) {
 #define GEMV_DISPATCH(WQ)                                                                                      \
     if (wq_bit == WQ)                                                                                          \
         return epi == EPI_F32 ? launch_gemv<WQ, EPI_F32>(s, x, w, scale, group, M, N, K, y, ldy)               \

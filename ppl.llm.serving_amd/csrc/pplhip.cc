@@ -1626,22 +1626,33 @@ int pplhip_op_rmsnorm(void* stream, const void* x, const void* skip, const void*
                                 hidden, nullptr, (uint16_t*)out, (uint16_t*)residual_out));
 }
 
-int pplhip_op_linear(void* stream, const void* x, const void* w, const void* scale, int32_t wq_bit, int32_t group, int64_t M,
-                     int32_t N, int32_t K, void* y, int32_t out_fp32) {
-    // split-K scratch of the stand-alone operator (the runtime owns its own per rank); one per device, never freed
+// split-K scratch of the stand-alone operators (the runtime owns its own per rank); one per device, never freed
+static float* op_linear_ws(size_t* bytes) {
     static float* ws[16] = {nullptr};
     static const size_t ws_bytes = (size_t)64 << 20;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return PPLHIP_DEVICE_RUNTIME_ERROR;
+    *bytes = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     if (!ws[dev] && hipMalloc((void**)&ws[dev], ws_bytes) != hipSuccess) ws[dev] = nullptr;
-    return op_rc(launch_linear((hipStream_t)stream, (const uint16_t*)x, w, (const uint16_t*)scale, wq_bit, group, M, N, K, y, N,
-                               out_fp32 != 0, ws[dev], ws[dev] ? ws_bytes : 0));
+    if (ws[dev]) *bytes = ws_bytes;
+    return ws[dev];
 }
 
+int pplhip_op_linear(void* stream, const void* x, const void* w, const void* scale, int32_t wq_bit, int32_t group, int64_t M,
+                     int32_t N, int32_t K, void* y, int32_t out_fp32) {
+    size_t ws_bytes = 0;
+    float* ws = op_linear_ws(&ws_bytes);
+    return op_rc(launch_linear((hipStream_t)stream, (const uint16_t*)x, w, (const uint16_t*)scale, wq_bit, group, M, N, K, y, N,
+                               out_fp32 != 0, ws, ws_bytes));
+}
+
+// (the same scratch: without it 4 <= M <= 256 ran unsplit -- N / 128 blocks instead of a full chip)
 int pplhip_op_linear_swiglu(void* stream, const void* x, const void* w, const void* scale, int32_t wq_bit, int32_t group, int64_t M,
                             int32_t N, int32_t K, void* y) {
+    size_t ws_bytes = 0;
+    float* ws = op_linear_ws(&ws_bytes);
     return op_rc(launch_linear((hipStream_t)stream, (const uint16_t*)x, w, (const uint16_t*)scale, wq_bit, group, M, N, K, y, N / 2,
-                               false, nullptr, 0, true));
+                               false, ws, ws_bytes, true));
 }
 
 int pplhip_op_rmsnorm_quant(void* stream, const void* x, const void* skip, const void* w, float eps, int64_t T, int32_t hidden,

@@ -1,0 +1,217 @@
+"""BASELINE configs 3 and 4 at THEIR OWN per-rank launch shapes: tests/test_gpu_tp.py runs the 13B/TP2 and
+70B/TP8 per-rank GEOMETRIES at batch 5-9, where the attention split heuristics and the M = 256 / 512 GEMM dispatch differ from what
+`bench.py --emulate-tp` launches.  Here the operators run at the configurations' batch sizes -- the pattern of test_gpu_config2_shape.py:
+
+  * config 3, one rank of LLaMA-2-13B at TP 2: decode attention B = 512, 20 local heads (multi-head), int8-g8 KV, kv 900..1100,
+    contiguous slots handed out in shuffled order; W8A16 GEMMs at M = 512 on the rank's four shapes (wqkv 7680 x 5120, wo 5120 x 2560,
+    w13 13824 x 5120 with the fused SwiGLU epilogue, w2 5120 x 6912);
+  * config 4, one rank of LLaMA-2-70B at TP 8: decode attention B = 256, 8 query heads over ONE KV head (grouped-query MFMA kernel),
+    int8-g8 KV, kv 1900..2100 on 16-token pages in shuffled order; W4A16-g128 GEMMs at M = 256 on the rank's four shapes (wqkv
+    1280 x 8192, wo 8192 x 1024, w13 7168 x 8192 + SwiGLU, w2 8192 x 3584).
+Attention against ref_attention on every row, GEMMs against ref_linear_raw on every row.
+  * config 5 at model level: the cache-prefill step (2048 new tokens behind 6144 cached ones, 16-token pages) of a 2-layer model with
+    LLaMA-2-7B's layer geometry, logits against the oracle (last test of the file)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import ref
+from tests.conftest import load_pplhip
+from tests.parity import record_err
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+D = 128
+PAGE = 16
+
+
+def f16(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float16)
+
+
+def _decode_attention_case(name, B, H, Hkv, kv_lo, kv_hi, mode, seed):
+    m = load_pplhip()
+    rng = np.random.RandomState(seed)
+    kv = rng.randint(kv_lo, kv_hi + 1, size=B).astype(np.int64)            # kv length INCLUDING the current token
+    start = kv - 1
+    desc = ref.make_desc(hidden_dim=H * D, intermediate_dim=64, num_layers=1, num_heads=H, num_kv_heads=Hkv, vocab_size=64,
+                         cache_quant_bit=8, cache_quant_group=8, cache_layout=3, cache_mode=mode, page_size=PAGE if mode else 0)
+    if mode == 0:
+        order = rng.permutation(B)
+        starts = np.concatenate([[0], np.cumsum(kv[order] + rng.randint(0, 40, size=B))[:-1]]) + 5
+        cache_idx = np.empty(B, dtype=np.int64)
+        cache_idx[order] = starts
+        n_slab = int((cache_idx + kv).max()) + 64
+        max_pages = 0
+    else:
+        npg = (kv + PAGE - 1) // PAGE
+        max_pages = int(npg.max())
+        n_pages = int(npg.sum()) + 37
+        pages = rng.permutation(n_pages)
+        cache_idx = np.full((B, max_pages), np.iinfo(np.int64).max, dtype=np.int64)
+        k = 0
+        for b in range(B):
+            cache_idx[b, :npg[b]] = pages[k:k + npg[b]]
+            k += npg[b]
+        n_slab = n_pages * PAGE
+    elems = n_slab * 2 * Hkv * D
+    cache = rng.randint(-127, 128, size=elems).astype(np.int8)
+    scale = f16(0.02 * (0.5 + rng.rand(elems // 8)))
+    seq = np.arange(B + 1, dtype=np.int64)
+    qkv = f16(rng.randn(B, (H + 2 * Hkv) * D))
+    rope = np.empty((kv_hi + 8, D), dtype=np.float32)
+    ref.lib().ref_build_rope_table(rope.ctypes.data, kv_hi + 8, D, 10000.0)
+    q32 = qkv.astype(np.float32)
+    # the current token's K / V go through the oracle's RoPE + quantising write into the slab both sides then read
+    ref.lib().ref_rope_kv_write(q32.ctypes.data, rope.ctypes.data, C.byref(desc), H, Hkv, D, 0, cache.ctypes.data, scale.ctypes.data,
+                                n_slab, seq.ctypes.data, start.ctypes.data, cache_idx.ctypes.data, max_pages, B)
+    want = np.zeros((B, H * D), dtype=np.float32)
+    ref.lib().ref_attention(q32.ctypes.data, C.byref(desc), H, Hkv, D, 0, cache.ctypes.data, scale.ctypes.data, n_slab,
+                            seq.ctypes.data, start.ctypes.data, cache_idx.ctypes.data, max_pages, B, want.ctypes.data)
+    dcache, dscale = torch.from_numpy(cache).cuda(), torch.from_numpy(scale).cuda()
+    v = m.KvView()
+    v.cache, v.scale = dcache.data_ptr(), dscale.data_ptr()
+    v.max_tokens, v.num_layers, v.kv_heads, v.head_dim = n_slab, 1, Hkv, D
+    v.quant_bit, v.quant_group, v.layout, v.mode, v.page_size, v.layer = 8, 8, 3, mode, PAGE if mode else 0, 0
+    dq = torch.from_numpy(q32.astype(np.float16)).cuda()
+    dseq, dsp, dci = torch.from_numpy(seq).cuda(), torch.from_numpy(start).cuda(), torch.from_numpy(cache_idx).cuda()
+    # the split the model runtime would choose for this launch (pplhip.cc: attn_split) is taken by the entry point when split_k = 0 is not
+    # offered; run the unsplit form and the runtime's usual split of 2 / 4, all against the oracle
+    for split in (1, 2, 4):
+        ws = torch.zeros(B * H * split * (D + 2), dtype=torch.float32, device="cuda")
+        out = torch.zeros((B, H * D), dtype=torch.float16, device="cuda")
+        rc = m.lib().pplhip_op_attention(None, dq.data_ptr(), C.byref(v), dseq.data_ptr(), dsp.data_ptr(), dci.data_ptr(), max_pages, B, B,
+                                         B, 1, int(kv.max()), H, split, ws.data_ptr(), ws.numel() * 4, out.data_ptr())
+        assert rc == 0
+        torch.cuda.synchronize()
+        got = out.float().cpu().numpy()
+        err = np.abs(got - want)
+        vmax = 0.03 * 127
+        record_err(f"{name}_split{split}", float(err.max()) / vmax, 1.5e-3)
+        bad = err > 1.5e-3 + 1.5e-3 * np.abs(want)
+        assert not bad.any(), (name, split, float(err.max()), int(bad.sum()))
+
+
+def test_config3_decode_attention_batch_512_20_heads_kv_1000():
+    """13B / TP 2 per rank: 20 of 40 heads, multi-head (attn_decode_kernel), kv 900..1100, contiguous slots"""
+    _decode_attention_case("config3_attn_decode_b512_h20", 512, 20, 20, 900, 1100, 0, 31)
+
+
+def test_config4_decode_attention_batch_256_gqa_8_to_1_kv_2000_paged():
+    """70B / TP 8 per rank: 8 query heads over one KV head (attn_decode_gqa_kernel), kv 1900..2100, shuffled 16-token pages"""
+    _decode_attention_case("config4_attn_decode_b256_gqa8", 256, 8, 1, 1900, 2100, 1, 41)
+
+
+def _linear_case(name, wq, M, N, K, swiglu, seed):
+    m = load_pplhip()
+    rng = np.random.RandomState(seed)
+    x = f16(rng.randn(M, K) * 0.5)
+    group = 128
+    if wq == 8:
+        w = rng.randint(-127, 128, size=(N, K)).astype(np.int8)
+        sc = f16(0.0003 * (0.5 + rng.rand(N)))
+    else:
+        w = rng.randint(0, 256, size=(N, K // 2)).astype(np.uint8)
+        sc = f16(0.006 * (0.5 + rng.rand(N, K // group)))
+    xs = x.astype(np.float32)
+    raw = np.empty((M, N), dtype=np.float32)
+    ref.lib().ref_linear_raw(xs.ctypes.data, w.ctypes.data, sc.ctypes.data, wq, group, M, N, K, raw.ctypes.data, 0)
+    dx = torch.from_numpy(x).cuda()
+    if swiglu:
+        inter = N // 2
+        want = np.empty((M, inter), dtype=np.float32)
+        ref.lib().ref_silu_mul(raw.ctypes.data, M, inter, want.ctypes.data)
+        perm = np.empty(N, dtype=np.int64)                                 # device layout: rows interleaved (gate_i, up_i)
+        perm[0::2], perm[1::2] = np.arange(inter), inter + np.arange(inter)
+        dw, dsc = torch.from_numpy(np.ascontiguousarray(w[perm])).cuda(), torch.from_numpy(np.ascontiguousarray(sc[perm])).cuda()
+        y = torch.empty((M, inter), dtype=torch.float16, device="cuda")
+        assert m.lib().pplhip_op_linear_swiglu(None, dx.data_ptr(), dw.data_ptr(), dsc.data_ptr(), wq, group, M, N, K, y.data_ptr()) == 0
+    else:
+        want = raw
+        dw, dsc = torch.from_numpy(w).cuda(), torch.from_numpy(sc).cuda()
+        y = torch.empty((M, N), dtype=torch.float16, device="cuda")
+        assert m.lib().pplhip_op_linear(None, dx.data_ptr(), dw.data_ptr(), dsc.data_ptr(), wq, group, M, N, K, y.data_ptr(), 0) == 0
+    torch.cuda.synchronize()
+    got = y.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    err = np.abs(got - want)
+    mag = float(np.abs(want).max())
+    # tolerances of tests/test_gpu_ops.py::test_linear / test_linear_swiglu_fused: fp32 accumulation-order noise, (W4) one fp16 rounding
+    # of q x scale per weight, (SwiGLU) two fp16 roundings upstream of the product
+    rel = (3e-3 if wq == 4 else 1.5e-3) * (2 if swiglu else 1)
+    record_err(name, float(err.max()) / mag, rel)
+    tol = rel * np.abs(want) + rel * mag * (0.25 if wq == 4 else 0.05) + 1e-5
+    assert (err <= tol).all(), (name, float(err.max()), mag, int((err > tol).sum()))
+    if wq == 8 and not swiglu:
+        assert (got == want).mean() > 0.97   # integer weights: the oracle's fp16 number bit for bit outside accumulation-order ties
+    return float((got == want).mean())
+
+
+@pytest.mark.parametrize("name,N,K,swiglu", [("wqkv", 7680, 5120, False), ("wo", 5120, 2560, False), ("w13", 2 * 6912, 5120, True),
+                                               ("w2", 5120, 6912, False)])
+def test_config3_w8a16_gemms_at_batch_512(name, N, K, swiglu):
+    _linear_case(f"config3_gemm_{name}_m512", 8, 512, N, K, swiglu, N + K)
+
+
+@pytest.mark.parametrize("name,N,K,swiglu", [("wqkv", 1280, 8192, False), ("wo", 8192, 1024, False), ("w13", 2 * 3584, 8192, True),
+                                               ("w2", 8192, 3584, False)])
+def test_config4_w4a16_gemms_at_batch_256(name, N, K, swiglu):
+    _linear_case(f"config4_gemm_{name}_m256", 4, 256, N, K, swiglu, N + K + 4)
+
+
+def test_config5_cache_prefill_2048_behind_6144_cached_tokens_vs_oracle():
+    """BASELINE config 5 at model level: a 2-layer model with LLaMA-2-7B's layer geometry (hidden 4096, 32
+    heads of 128, inter 11008), W8A16, int8-g8 KV on shuffled 16-token pages; an 8192-token prompt whose first 6144 tokens are already
+    cached.  The DEVICE prefills the 6144-token prefix (a cold prefill, checked elsewhere: tests/test_gpu_fulldepth.py, test_gpu_ops.py)
+    and its KV slab is copied into the oracle, so both sides enter the step in question with identical caches; then the CACHE-PREFILL of
+    the remaining 2048 tokens at start_pos 6144 (what a prefix-cache hit leaves to compute: 384 cached pages + 128 new ones) runs on
+    both -- logits against the oracle, with the oracle's noise floor in another summation order on the same inputs; the K / V bytes the
+    step appends are compared as well."""
+    from tests.parity import oracle_noise
+    m = load_pplhip()
+    P, SH, TOT = 16, 6144, 8192
+    desc = ref.make_desc(hidden_dim=4096, intermediate_dim=11008, num_layers=2, num_heads=32, num_kv_heads=32, vocab_size=4096,
+                         max_position=TOT + 64, cache_quant_bit=8, cache_quant_group=8, cache_layout=3, cache_mode=1, page_size=P,
+                         weight_quant_bit=8, weight_quant_group=128)
+    rm = ref.RefModel(desc)
+    rm.init_synthetic(77)
+    ctx = m.Context(m.copy_desc(desc), max_running_batch=2, max_tokens_per_step=SH)
+    ctx.init_synthetic(0, 77)
+    n_tok = 2 * TOT
+    rm.kv_alloc(n_tok)
+    ctx.kv_alloc(0, n_tok)
+    try:
+        rng = np.random.RandomState(9)
+        prompt = rng.randint(3, 4096, size=TOT).astype(np.int64)
+        npg = TOT // P
+        pages = rng.permutation(n_tok // P)[:npg].reshape(1, npg)  # 384 pages of the cached prefix + 128 for the tail, shuffled
+        # the prefix goes into the cache on the device; the oracle takes the device's slab
+        ctx.set_inputs(0, m.make_step(prompt[:SH], [0, SH], [0], pages, 0, npg))
+        ctx.run(0)
+        for which in (0, 1):
+            rm.kv_array(which)[:] = ctx.kv_read(0, which)
+        # cache-prefill of the 2048-token tail
+        rm_st, dv_st = ref.make_step(prompt[SH:], [0, TOT - SH], [SH], pages, 0, npg), m.make_step(prompt[SH:], [0, TOT - SH], [SH], pages, 0, npg)
+        want = ref.forward([rm], rm_st)
+        alt = oracle_noise([rm], rm_st)
+        ctx.set_inputs(0, dv_st)
+        ctx.run(0, cache_prefill=1)
+        got = ctx.copy_logits(1)
+        scale = max(1.0, float(np.abs(want).max()))
+        noise = float(np.abs(alt - want).max()) / scale
+        err = float(np.abs(got - want).max()) / scale
+        rel = max(1e-3, 2.5 * noise)                                        # the bar of tests/test_gpu_model.py (NOISE_RATIO)
+        record_err("config5_cache_prefill_2048_behind_6144_logits", err, min(rel, 4e-3), noise=noise)
+        assert err <= min(rel, 4e-3), (err, noise)
+        srt = np.sort(want[0])
+        if srt[-1] - srt[-2] > 2 * rel * scale:                             # greedy token of the answer
+            assert got[0].argmax() == want[0].argmax()
+        # the int8 K / V bytes and scales the step appended (and everything it must not have touched): a few LSB on few bytes
+        gk, rk = ctx.kv_read(0, 0), rm.kv_array(0)
+        assert (np.abs(gk.astype(np.int32) - rk.astype(np.int32)) <= 3).all()
+        assert (gk != rk).mean() < 0.02
+    finally:
+        ctx.close()
+        rm.close()

@@ -54,29 +54,43 @@ def _layer_errs(got, want):
     return [_rel(got[l], want[l]) for l in range(got.shape[0])]
 
 
-# The bar at full depth.  Two CORRECT fp16 implementations of the specification -- the oracle, and the oracle with its fp32 dot
-# products summed in another order -- drift apart by ~1.3e-2 of the logit scale over these 32 layers with int8 KV (6e-3 with
-# fp16 KV): the residual stream is rounded to fp16 64 times, every flipped rounding is carried to the end, and a flipped int8
-# cache byte is worth eight fp16 roundings (profiles/r03_fulldepth_probe.txt).  "Within 1e-3" therefore cannot be asked of ANY
-# implementation at this depth; what is asked of the device is
-#   (a) to be no further from the oracle than RATIO_NOISE x that noise floor, measured on the same inputs in the same test,
-#       for the logits and for the residual stream after every layer, and
-#   (b) to be no further from EXACT arithmetic (the oracle with fp32 activations and double accumulation, the mode pinned
-#       against HuggingFace at 1e-5) than RATIO_EXACT x the fp16 oracles are.
-# RATIO_EXACT: x_ref is the larger of only TWO samples (two summation orders of the oracle) of a random quantity whose samples differ by
-# 10-15 % between orders; the device is a third order (and its order changes with the kernel a batch size selects: at batch 6 the GEMMs
-# moved from the skinny kernel to split-K half-height tiles in round 3 and the fp16 / fp16-KV step-1 ratio went 1.11 -> 1.22).  Observed
-# over all steps and both configurations: 0.84 .. 1.22.
+# The bar at full depth.  CORRECT fp16 implementations of the specification -- the oracle, and the oracle with its fp32 dot products
+# summed in two other orders -- drift apart by ~1.3e-2 of the logit scale over these 32 layers with int8 KV (6e-3 with fp16 KV): the
+# residual stream is rounded to fp16 64 times, every flipped rounding is carried to the end, and a flipped int8 cache byte is worth
+# eight fp16 roundings (profiles/r03_fulldepth_probe.txt).  "Within 1e-3" therefore cannot be asked of ANY implementation at this
+# depth; what is asked of the device is
+#   (a) to be no further from the oracle than RATIO_NOISE x that noise floor, measured on the same inputs in the same test, for the
+#       logits and for the residual stream after every layer, and
+#   (b) to be no further from EXACT arithmetic (the oracle with fp32 activations and double accumulation, the mode pinned against
+#       HuggingFace at 1e-5) than RATIO_EXACT x the fp16 oracles are.
+# Round 4: the noise floor is the LARGEST of the three pairwise distances between three summation orders of the
+# oracle (it was one distance between two), x_ref the largest of three oracle-vs-exact distances, and the ratios are FROZEN at the values
+# below -- a kernel change that needs them raised is a regression to explain, not a bound to move.  Observed with three orders:
+# profiles/r04_parity_errors.jsonl.
 RATIO_NOISE_LOGITS, RATIO_NOISE_HIDDEN, RATIO_EXACT = 1.4, 1.6, 1.35
+# greedy tokens: with synthetic weights the top-2 margin of a row is a few per cent of the logit scale, the order
+# of the noise floor, so "equal wherever the margin is safe" compared few rows or none.  The lm_head rows of 24 chosen tokens are therefore
+# ENGINEERED from the oracle's own final hidden states (teacher-forced on the chosen continuation) so that row (request r, step s) has
+# its chosen token MARGIN_X safety thresholds above every other token; the greedy continuation of both sides must then BE the chosen
+# tokens, and MIN_SAFE_FRACTION of the rows must be compared token for token (asserted and logged).
+MARGIN_X, MIN_SAFE_FRACTION = 4.0, 0.75
 
 
-def _traces(m, rm, ctx):
-    """packed prefill + 3 greedy decode steps, four ways: oracle (the specification), device, oracle in another summation
-    order, oracle in exact arithmetic; the specification's greedy tokens feed all of them"""
+def _final_norm(rm, resid):
+    w = rm.get_tensor("norm.weight", np.float16).astype(np.float64)
+    r = resid.astype(np.float64)
+    return r / np.sqrt((r * r).mean(-1, keepdims=True) + float(rm.desc.norm_eps)) * w
+
+
+def _traces(m, rm, ctx, name):
+    """packed prefill + 3 greedy decode steps, five ways: oracle (the specification), device, the oracle in two other summation
+    orders, oracle in exact arithmetic; the specification's greedy tokens feed all of them"""
     rng = np.random.RandomState(11)
-    prompts = [rng.randint(3, DIMS["vocab_size"], size=n).astype(np.int64) for n in PROMPT_LENS]
+    V = DIMS["vocab_size"]
+    prompts = [rng.randint(3, V, size=n).astype(np.int64) for n in PROMPT_LENS]
     n = len(prompts)
     cache_idx = (np.arange(n) * 128).astype(np.int64)
+    chosen = (1000 + 37 * np.arange(4 * n)).reshape(4, n).astype(np.int64)   # the continuation the engineered lm_head must produce
 
     def trace(runner, feed=None):
         tok = np.concatenate(prompts)
@@ -85,7 +99,7 @@ def _traces(m, rm, ctx):
         out = []
         for s in range(4):
             logits, dump = runner(tok, seq, sp, 0 if s == 0 else n, s)
-            out.append((logits, dump))
+            out.append((logits, dump, seq[1:] - 1))
             nxt = logits.argmax(-1) if feed is None else feed[s]
             sp = sp + (seq[1:] - seq[:-1])
             tok = nxt.astype(np.int64)
@@ -100,6 +114,30 @@ def _traces(m, rm, ctx):
         dump = ctx.run_dump(0, len(tok))
         return ctx.copy_logits(n), dump
 
+    # ---- phase A: teacher-forced on the chosen tokens with the synthetic lm_head: final hidden states of the 24 (row, step) pairs and a
+    # first noise estimate; then the chosen tokens' lm_head rows are solved for (least-norm W with W . Y^T = T)
+    rm.kv_alloc(KV_TOKENS)
+    a_spec = trace(oracle, chosen)
+    with ref.mode(ref.MODE_ALT_ORDER):
+        rm.kv_alloc(KV_TOKENS)
+        a_alt = trace(oracle, chosen)
+    noise0 = max(_rel(a_alt[s][0], a_spec[s][0]) for s in range(4))
+    Y = np.concatenate([_final_norm(rm, a_spec[s][1][-1][a_spec[s][2]]) for s in range(4)])      # [4 n, hidden], row p = s * n + r
+    other = np.concatenate([a_spec[s][0] for s in range(4)]).astype(np.float64)                  # [4 n, V]
+    other[:, chosen.reshape(-1)] = -np.inf
+    top_other = other.max(-1)
+    scale = max(1.0, float(np.abs(np.concatenate([a_spec[s][0] for s in range(4)])).max()))
+    margin = MARGIN_X * 2 * RATIO_NOISE_LOGITS * noise0 * scale
+    T = np.zeros((4 * n, 4 * n))
+    T[np.arange(4 * n), np.arange(4 * n)] = top_other + margin
+    W = (T @ np.linalg.inv(Y @ Y.T) @ Y).astype(np.float16)
+    head = rm.get_tensor("output.weight", np.float16).reshape(V, -1).copy()
+    head[chosen.reshape(-1)] = W
+    rm.set_tensor("output.weight", head)
+    ctx.set_tensor(0, "output.weight", head)
+    _layer_log(f"{name}_engineered_head", [noise0, margin / scale, float(np.abs(W.astype(np.float32)).max())])
+
+    # ---- phase B: the comparison proper
     rm.kv_alloc(KV_TOKENS)
     spec = trace(oracle)
     feed = [o[0].argmax(-1) for o in spec]
@@ -107,18 +145,25 @@ def _traces(m, rm, ctx):
     with ref.mode(ref.MODE_ALT_ORDER):
         rm.kv_alloc(KV_TOKENS)
         alt = trace(oracle, feed)
+    with ref.mode(ref.MODE_ALT_ORDER2):
+        rm.kv_alloc(KV_TOKENS)
+        alt2 = trace(oracle, feed)
     with ref.mode(ref.MODE_FP32_ACT | ref.MODE_F64_ACC):
         rm.kv_alloc(KV_TOKENS)
         exact = trace(oracle, feed)
-    return spec, dev, alt, exact
+    return spec, dev, alt, alt2, exact, chosen
 
 
-def _check(name, spec, dev, alt, exact):
+def _check(name, spec, dev, alt, alt2, exact, chosen):
+    n_safe = n_rows = 0
     for s in range(4):
-        e_dev, e_noise = _rel(dev[s][0], spec[s][0]), _rel(alt[s][0], spec[s][0])
+        e_dev = _rel(dev[s][0], spec[s][0])
+        e_noise = max(_rel(alt[s][0], spec[s][0]), _rel(alt2[s][0], spec[s][0]), _rel(alt2[s][0], alt[s][0]))
         x_dev = _rel(dev[s][0], exact[s][0])
-        x_ref = max(_rel(spec[s][0], exact[s][0]), _rel(alt[s][0], exact[s][0]))
-        h_dev, h_noise = _layer_errs(dev[s][1], spec[s][1]), _layer_errs(alt[s][1], spec[s][1])
+        x_ref = max(_rel(spec[s][0], exact[s][0]), _rel(alt[s][0], exact[s][0]), _rel(alt2[s][0], exact[s][0]))
+        h_dev = _layer_errs(dev[s][1], spec[s][1])
+        h_noise = [max(a, b, c) for a, b, c in zip(_layer_errs(alt[s][1], spec[s][1]), _layer_errs(alt2[s][1], spec[s][1]),
+                                                   _layer_errs(alt2[s][1], alt[s][1]))]
         _layer_log(f"{name}_step{s}_device_vs_oracle", h_dev)
         _layer_log(f"{name}_step{s}_oracle_noise_floor", h_noise)
         record_err(f"fulldepth_{name}_step{s}_logits", e_dev, RATIO_NOISE_LOGITS * e_noise, noise=e_noise)
@@ -128,11 +173,17 @@ def _check(name, spec, dev, alt, exact):
         assert x_dev <= RATIO_EXACT * x_ref, (name, s, x_dev, x_ref)
         for l in range(1, len(h_dev)):
             assert h_dev[l] <= RATIO_NOISE_HIDDEN * max(h_noise[l], 1e-3), (name, s, l, h_dev[l], h_noise[l])
-        # greedy tokens: equal wherever the specification's top-2 margin is outside twice the noise floor
+        # greedy tokens: equal wherever the specification's top-2 margin is outside twice the tolerance -- by construction of the
+        # lm_head (MARGIN_X) that is nearly every row, and the continuation is the chosen one
         want = spec[s][0]
         srt = np.sort(want, -1)
         safe = (srt[:, -1] - srt[:, -2]) > 2 * RATIO_NOISE_LOGITS * e_noise * max(1.0, float(np.abs(want).max()))
+        n_safe += int(safe.sum())
+        n_rows += len(safe)
         assert (dev[s][0].argmax(-1)[safe] == want.argmax(-1)[safe]).all(), (name, s)
+        assert (want.argmax(-1)[safe] == chosen[s][safe]).all(), (name, s)
+    record_err(f"fulldepth_{name}_greedy_rows_compared_fraction", n_safe / n_rows, MIN_SAFE_FRACTION)
+    assert n_safe >= MIN_SAFE_FRACTION * n_rows, (name, n_safe, n_rows)
 
 
 def test_7b_w8a16_int8kv_32_layers_vs_oracle():
@@ -140,7 +191,7 @@ def test_7b_w8a16_int8kv_32_layers_vs_oracle():
     m = load_pplhip()
     desc, rm, ctx = _pair(m, wq=8, kvq=8)
     try:
-        _check("w8a16_int8kv", *_traces(m, rm, ctx))
+        _check("w8a16_int8kv", *_traces(m, rm, ctx, "w8a16_int8kv"))
     finally:
         ctx.close()
         rm.close()
@@ -151,7 +202,7 @@ def test_7b_fp16_fp16kv_32_layers_vs_oracle():
     m = load_pplhip()
     desc, rm, ctx = _pair(m, wq=0, kvq=0)
     try:
-        _check("fp16_fp16kv", *_traces(m, rm, ctx))
+        _check("fp16_fp16kv", *_traces(m, rm, ctx, "fp16_fp16kv"))
     finally:
         ctx.close()
         rm.close()

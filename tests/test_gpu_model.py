@@ -83,6 +83,7 @@ def generate_both(m, ctx, models, desc, prompts, steps, max_tokens):
 
 
 NOISE_RATIO = 2.5
+MIN_SAFE_FRACTION = 0.75
 
 
 def check_steps(res, k, name=None):
@@ -90,6 +91,7 @@ def check_steps(res, k, name=None):
         name = os.environ.get("PYTEST_CURRENT_TEST", "?").split("::")[-1].split(" ")[0]
     # the noise floor of the TRACE (largest over its steps): the device's KV slab carries its differences from step to step
     noise = max(float(np.abs(r[6] - r[1]).max() / max(1.0, np.abs(r[1]).max())) for r in res)
+    n_safe = n_rows = 0
     for s, (got, want, gtok, wtok, glp, wlp, alt) in enumerate(res):
         scale = max(1.0, np.abs(want).max())
         rel = min(1e-3 * k, max(1e-3, NOISE_RATIO * noise)) if noise > 1e-5 else 1e-3 * k   # (integer GEMMs have no summation-order noise)
@@ -99,8 +101,15 @@ def check_steps(res, k, name=None):
         assert err <= tol, (s, err / scale, rel, noise)
         srt = np.sort(want, -1)
         safe = (srt[:, -1] - srt[:, -2]) > 2 * tol
+        n_safe += int(safe.sum())
+        n_rows += len(safe)
         assert (gtok[safe] == wtok[safe]).all(), s
-        assert np.abs(glp[safe] - wlp[safe]).max() < 5 * tol
+        if safe.any():
+            assert np.abs(glp[safe] - wlp[safe]).max() < 5 * tol
+    # the greedy-token comparison must not be vacuous: most rows of the trace have a top-2 margin outside
+    # twice the tolerance and ARE compared token for token; the fraction goes to the parity log
+    record_err(name + ":greedy_rows_compared_fraction", n_safe / n_rows, MIN_SAFE_FRACTION)
+    assert n_safe >= MIN_SAFE_FRACTION * n_rows, (name, n_safe, n_rows)
 
 
 @pytest.mark.parametrize("name", ["mha", "gqa"])

@@ -382,19 +382,15 @@ def test_attention_long_prefill_and_cache_prefill(quant, seqlens, start, heads, 
     close_f16(got, want, rel=1e-3, abs_=1e-3 * vmax)   # observed (r02) <= 5.1e-4 |V|max
 
 
-@pytest.mark.parametrize("quant", [8, 0])
-@pytest.mark.parametrize("seqlens,start,heads,mode", [([16], [8176], (8, 1), 1), ([7, 16, 1], [2000, 5000, 4097], (4, 4), 0),
-                                                        ([32, 3], [1000, 1500], (2, 2), 1),
-                                                        ([300, 129], [2500, 900], (4, 4), 1), ([600], [1800], (2, 2), 0)])  # several query blocks
-def test_attention_short_suffix_split_kv(quant, seqlens, start, heads, mode):
-    """cache-prefill of a few new tokens behind a long cached prefix (what a prefix-cache hit leaves to compute): with a workspace the
-    launcher splits the keys over several blocks per (request, head) and merges the partial rows -- against the oracle, and equal
-    (to fp16 rounding of the merge) to the unsplit kernel."""
+def _split_kv_case(quant, seqlens, start, heads, mode, nb=0):
+    """one cache-prefill launch with and without the split-KV workspace, against the oracle.  The workspace is sized for the prefill
+    rows ONLY (the launcher's contract) and followed by a canary region: decode rows ahead of the prefill requests must not shift the
+    partial rows past its end."""
     m = load_pplhip()
     H, Hkv = heads
     D = 128
     case = KvCase(m, H, Hkv, D, L=1, layer=0, quant=quant, layout=3, mode=mode, seqlens=seqlens, start_pos=start,
-                  seed=len(seqlens) + quant + H, page_size=16, decoding_batches=0)
+                  seed=len(seqlens) + quant + H, page_size=16, decoding_batches=nb)
     rng = np.random.RandomState(23)
     if quant:
         case.cache[:] = rng.randint(-127, 128, size=case.cache.size).astype(np.int8)
@@ -406,19 +402,61 @@ def test_attention_short_suffix_split_kv(quant, seqlens, start, heads, mode):
     dq = dev(q32.astype(np.float16))
     dcache, dscale = dev(case.cache), (dev(case.scale) if quant else None)
     v = case.view(dcache, dscale)
-    ws = torch.zeros(case.T * H * 32 * (D + 2), dtype=torch.float32, device="cuda")
+    n_ws = (case.T - nb) * H * 32 * (D + 2)
+    n_guard = (nb + 8) * H * 32 * (D + 2)
+    ws = torch.zeros(n_ws + n_guard, dtype=torch.float32, device="cuda")
+    ws[n_ws:] = 12345.0
     outs = []  # (first with the workspace: split-KV; then without: one block per (query block, request, head))
-    for wsp, wsb in ((ws.data_ptr(), ws.numel() * 4), (None, 0)):
+    for wsp, wsb in ((ws.data_ptr(), n_ws * 4), (None, 0)):
         out = torch.zeros((case.T, H * D), dtype=torch.float16, device="cuda")
         ck(m.lib().pplhip_op_attention(None, dq.data_ptr(), C.byref(v), dev(case.seq_starts).data_ptr(), dev(case.start_pos).data_ptr(),
-                                       dev(case.cache_idx).data_ptr(), case.max_pages, case.B, case.T, 0, case.max_seq_len,
+                                       dev(case.cache_idx).data_ptr(), case.max_pages, case.B, case.T, nb, case.max_seq_len,
                                        case.max_kv_len, H, 1, wsp, wsb, out.data_ptr()))
         outs.append(out.cpu().numpy().astype(np.float32))
-    assert float(ws.abs().max()) > 0, "the split-KV path did not run"
+    assert float(ws[:n_ws].abs().max()) > 0, "the split-KV path did not run"
+    assert bool((ws[n_ws:] == 12345.0).all()), "the split-KV kernel wrote past its workspace"
+    assert np.isfinite(outs[0]).all()
     vmax = 3.0 if not quant else 0.03 * 127
     close_f16(outs[0], want, rel=1e-3, abs_=1e-3 * vmax)
     close_f16(outs[1], want, rel=1e-3, abs_=1e-3 * vmax)
     close_f16(outs[0], outs[1], rel=2e-3, abs_=2e-4 * vmax)
+
+
+@pytest.mark.parametrize("quant", [8, 0])
+@pytest.mark.parametrize("seqlens,start,heads,mode", [([16], [8176], (8, 1), 1), ([7, 16, 1], [2000, 5000, 4097], (4, 4), 0),
+                                                        ([32, 3], [1000, 1500], (2, 2), 1),
+                                                        ([300, 129], [2500, 900], (4, 4), 1), ([600], [1800], (2, 2), 0)])  # several query blocks
+def test_attention_short_suffix_split_kv(quant, seqlens, start, heads, mode):
+    """cache-prefill of a few new tokens behind a long cached prefix (what a prefix-cache hit leaves to compute): with a workspace the
+    launcher splits the keys over several blocks per (request, head) and merges the partial rows -- against the oracle, and equal
+    (to fp16 rounding of the merge) to the unsplit kernel."""
+    _split_kv_case(quant, seqlens, start, heads, mode)
+
+
+@pytest.mark.parametrize("quant", [8, 0])
+@pytest.mark.parametrize("seqlens,start,heads,mode,nb", [([1, 1, 1, 1, 1, 16, 9], [1500, 1200, 3000, 1100, 2000, 4000, 2050], (4, 4), 1, 5),
+                                                           ([1] * 40 + [100], list(range(600, 640)) + [8000], (4, 2), 0, 40)])
+def test_attention_split_kv_behind_decode_rows(quant, seqlens, start, heads, mode, nb):
+    """a continuous-batching step: decode requests (one row each) AHEAD of a short-suffix prefill request.  The partial rows of the
+    split-KV form are indexed relative to the launch's first row (they were indexed by the absolute token row and ran
+    past a workspace sized for the prefill rows)."""
+    _split_kv_case(quant, seqlens, start, heads, mode, nb)
+
+
+@pytest.mark.parametrize("quant", [8, 0])
+def test_attention_split_kv_first_tile_masked(quant):
+    """PPLHIP_P32_SPLIT forces one 64-key tile per split, so that a split STARTS on the tile in which some rows of a wave see no key
+    (start_pos + rows crossing a 64-key boundary): those rows must contribute p = 0 and keep their initial state (the mask
+    value equalled the running maximum's initial value).  The switch is read once per process: run in a child."""
+    import subprocess, sys, os
+    code = ("import tests.test_gpu_ops as t\n"
+            f"t._split_kv_case({quant}, [32, 40], [1072, 1101], (2, 2), 0)\n"
+            f"t._split_kv_case({quant}, [32], [1136], (2, 1), 1)\n"
+            "print('SPLIT-OK')\n")
+    env = dict(os.environ, PPLHIP_P32_SPLIT="19")
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SPLIT-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 def test_sampler_greedy_and_topk():
