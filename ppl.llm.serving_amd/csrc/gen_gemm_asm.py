@@ -24,6 +24,9 @@ after the statement: the statement ends with 24 wait states.
 import sys
 
 NI = int(sys.argv[1]) if len(sys.argv) > 1 else 3           # weight row blocks of 32 per wave
+ABL = int(sys.argv[2]) if len(sys.argv) > 2 else 0          # diagnosis builds (WRONG results): 1 no fragment reads in the loop, 2 no conversion, 4 no barrier
+ST = int(sys.argv[3]) if len(sys.argv) > 3 else 3            # ring stages
+PRIO = int(sys.argv[4]) if len(sys.argv) > 4 else 0          # s_setprio of the consumer waves
 XB = 128 * 64 * 2                                           # activation bytes per ring stage
 WB = 4 * 32 * NI * 64                                       # weight bytes per ring stage (4 consumer waves)
 NJ = 4
@@ -51,14 +54,17 @@ class Gen:
     def __init__(self):
         self.lines = []
         self.q = []          # outstanding LDS reads, issue order
+        self.in_loop = False
 
     def emit(self, s): self.lines.append(s)
 
     def ds_x(self, slot, s, j, tag):
+        if (ABL & 1) and self.in_loop: return
         self.emit(f"ds_read_b128 {vr(V_X[slot], 4)}, v{V_XA[s]} offset:{j * 4096}")
         self.q.append(tag)
 
     def ds_w(self, s, i, tag):
+        if (ABL & 1) and self.in_loop: return
         self.emit(f"ds_read_b64 {vr(V_RAW[i], 2)}, v{V_WA[s]} offset:{i * 2048}")
         self.q.append(tag)
 
@@ -78,6 +84,7 @@ class Gen:
     def cvt_ops(self, wset, i):
         """the 10 VALU ops that turn raw fragment i (8 int8 per lane) into 8 fp16 in converted set `wset`"""
         r, d = V_RAW[i], V_WC[wset][i]
+        if (ABL & 2) and self.in_loop: return []
         ops = [f"v_xor_b32_e32 v{r}, 0x80808080, v{r}", f"v_xor_b32_e32 v{r + 1}, 0x80808080, v{r + 1}"]
         ops += [f"v_perm_b32 v{d}, v{V_C64}, v{r}, s{S_SEL0}", f"v_perm_b32 v{d + 1}, v{V_C64}, v{r}, s{S_SEL1}",
                 f"v_perm_b32 v{d + 2}, v{V_C64}, v{r + 1}, s{S_SEL0}", f"v_perm_b32 v{d + 3}, v{V_C64}, v{r + 1}, s{S_SEL1}"]
@@ -119,9 +126,9 @@ def body(g, last_tile):
             # behind the first MFMA: every read of this tile has landed -> barrier -> the ring moves on -> first reads of the next tile
             def sync():
                 g.wait_all()
-                g.emit("s_barrier")
+                if not (ABL & 4): g.emit("s_barrier")
                 g.emit(f"s_add_u32 s{S_STAGE}, s{S_STAGE}, 1")
-                g.emit(f"s_cmp_eq_u32 s{S_STAGE}, 3")
+                g.emit(f"s_cmp_eq_u32 s{S_STAGE}, {ST}")
                 g.emit(f"s_cselect_b32 s{S_DX}, s{S_XBN}, s{S_XBP}")
                 g.emit(f"s_cselect_b32 s{S_DW}, s{S_WBN}, s{S_WBP}")
                 g.emit(f"s_cselect_b32 s{S_STAGE}, 0, s{S_STAGE}")
@@ -147,6 +154,9 @@ def body(g, last_tile):
                     for o in ops[lo:hi]: g.emit(o)
                 return f
             k = 0
+            if not ops:
+                add(cvt_from, lambda: g.wait(("W", NI - 1)))
+                slots = []
             for m in slots:
                 if k >= len(ops): break
                 add(m, chunk(k, min(k + per, len(ops))))
@@ -159,10 +169,11 @@ def generate():
     g = Gen()
     e = g.emit
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    if PRIO: e(f"s_setprio {PRIO}")
     # constants, addresses
     e(f"s_mov_b32 s{S_SEL0}, 0x04010400"); e(f"s_mov_b32 s{S_SEL1}, 0x04030402"); e(f"s_mov_b32 s{S_BIAS}, 0xe480e480")
-    e(f"s_mov_b32 s{S_XBP}, {XB}"); e(f"s_mov_b32 s{S_XBN}, {-2 * XB & 0xffffffff:#x}")
-    e(f"s_mov_b32 s{S_WBP}, {WB}"); e(f"s_mov_b32 s{S_WBN}, {-2 * WB & 0xffffffff:#x}")
+    e(f"s_mov_b32 s{S_XBP}, {XB}"); e(f"s_mov_b32 s{S_XBN}, {-(ST - 1) * XB & 0xffffffff:#x}")
+    e(f"s_mov_b32 s{S_WBP}, {WB}"); e(f"s_mov_b32 s{S_WBN}, {-(ST - 1) * WB & 0xffffffff:#x}")
     e(f"s_mov_b32 s{S_STAGE}, 0")
     e(f"s_sub_u32 s{S_CNT}, %{4 * NI + 2}, 1")
     e(f"v_mov_b32_e32 v{V_C64}, 0x64646464")
@@ -190,7 +201,10 @@ def generate():
     e("s_cbranch_scc1 2f")
     e(".p2align 6")
     e("1:")
+    g.in_loop = True
     body(g, last_tile=False)
+    g.in_loop = False
+    if ABL & 1: g.q = list(entry_q)
     assert g.q == entry_q, (g.q, entry_q)            # the loop's back edge sees the queue it was entered with
     e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
     e(f"s_cmp_lg_u32 s{S_CNT}, 0")
@@ -206,7 +220,7 @@ def main():
     lines = generate()
     n_mfma = sum(1 for l in lines if l.startswith("v_mfma"))
     clob = [f"v{r}" for r in range(LOW, 256)] + [f"s{r}" for r in range(S_CNT, S_WBN + 1)] + ["scc", "memory"]
-    out = [f"// GENERATED by gen_gemm_asm.py {NI} -- do not edit.  {len(lines)} lines, {n_mfma} MFMAs; physical registers v{LOW}..v255.",
+    out = [f"// GENERATED by gen_gemm_asm.py {NI} {ABL} {ST} {PRIO} -- do not edit.  {len(lines)} lines, {n_mfma} MFMAs; physical registers v{LOW}..v255.",
            f"// operands: %0..%{4 * NI - 1} accumulators (j-major), %{4 * NI} xa0, %{4 * NI + 1} wa0 (VGPR), %{4 * NI + 2} ktiles (SGPR)",
            f"#define GEMM_ASM_NI{NI}_LOW_VGPR {LOW}",
            f"#define GEMM_ASM_NI{NI}_TEXT \\"]

@@ -495,6 +495,10 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
     static const int wide = getenv("PPLHIP_GEMM_WIDE") ? atoi(getenv("PPLHIP_GEMM_WIDE")) : 1;
     if (wide && wq_bit == 8 && K % G_BK == 0 && M >= 512 && (M < 4096 || wide == 2) && N >= 8192) {
         const int nc = wide == 2 ? 12 : linear_w8_wide_waves(M, N);  // (2: experiments -- every eligible shape, any M)
+        // PPLHIP_GEMM_ASM=1: the same block tile on the hand-scheduled K loop of k_gemm_asm.hip (round 4).  Equal speed on random
+        // operands -- both kernels sit on the chip's power limit, profiles/r04_gemm_asm_experiments.md -- so it is not the default
+        static const int asm_loop = getenv("PPLHIP_GEMM_ASM") ? atoi(getenv("PPLHIP_GEMM_ASM")) : 0;
+        if (nc && asm_loop) return launch_linear_w8_asm(s, x, (const int8_t*)w, scale, M, N, K, y, ldy, epi);
         if (nc) return launch_linear_w8_wide(s, x, (const int8_t*)w, scale, M, N, K, y, ldy, epi, nc);
     }
     const int n_tiles = (N + G_BN - 1) / G_BN;
