@@ -480,6 +480,9 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
     // the skinny kernel up to 3 rows; from 4 rows the half-height tile kernel (64 activation rows, split-K) is faster: 7B decode step at batch
     // 4 / 8 / 12 / 16 3.64 / 3.90 / 4.40 / 4.74 -> 3.56 / 3.73 / 3.81 / 4.18 ms (profiles/small_batch_latency.py); PPLHIP_GEMV_MAX_M overrides
     static const int gemv_max_m = getenv("PPLHIP_GEMV_MAX_M") ? atoi(getenv("PPLHIP_GEMV_MAX_M")) : 3;
+    // up to 4 rows (PPLHIP_GEMV_STREAM_MAX_M): the streaming GEMV of k_gemv.hip -- whole 1-KiB row pieces per wave-load, no matrix unit
+    if (M <= gemv_stream_max_m(wq_bit, group, N, K) && !no_skinny && !force_generic)
+        return launch_gemv_stream(s, x, w, scale, wq_bit, group, M, N, K, y, ldy, epi);
     // (without a split-K workspace the half-height tiles would run as N / 128 unsplit blocks: the skinny kernel keeps its 16 rows there)
     if (M <= (ws && ws_bytes ? gemv_max_m : 16) && M <= 16 && !no_skinny) {
 #define GEMV_DISPATCH(WQ)                                                                                      \

@@ -70,6 +70,10 @@ int linear_w8_wide_waves(int64_t M, int N);  // 12 when the 128 x 384 tiles fill
 hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const uint16_t* scale, int wq_bit, int group,
                          int64_t M, int N, int K, void* y, int64_t ldy, bool out_fp32, float* ws = nullptr, size_t ws_bytes = 0,
                          bool swiglu = false);
+// ---- k_gemv.hip: streaming GEMV, 1 <= M <= 4 (whole 1-KiB row pieces per wave-load; VALU dot products) ----------------------------
+int gemv_stream_max_m(int wq_bit, int group, int N, int K);  // largest M the kernel takes for this shape (0: none)
+hipError_t launch_gemv_stream(hipStream_t s, const uint16_t* x, const void* w, const uint16_t* scale, int wq_bit, int group, int64_t M, int N,
+                              int K, void* y, int64_t ldy, int epi);
 // ---- k_gemm_i8.hip: online_i8i8 (W8A8) ------------------------------------------------------------
 // per-token int8 activations: q [M, ldq] (columns K..ldq-1 zeroed), sx [M] = max|x| / 127
 hipError_t launch_quant_act(hipStream_t s, const uint16_t* x, int64_t M, int K, int64_t ldx, int8_t* q, int64_t ldq, float* sx);

@@ -554,3 +554,18 @@ def test_linear_swiglu_fused(wq, M, inter, K):
     mag = np.abs(want).max()
     rel = 6e-3 if wq == 4 else 3e-3   # two fp16 roundings upstream of the product
     close_f16(y.cpu().numpy(), want, rel=rel, abs_=rel * mag * (0.25 if wq == 4 else 0.05) + 1e-5)
+
+
+@pytest.mark.parametrize("wq", [0, 8, 4])
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (12288, 4096), (4096, 11008), (1000, 384), (52, 128), (2000, 9600), (640, 24576)])
+def test_linear_streaming_gemv(wq, M, N, K):
+    """1 <= M <= 4: the streaming GEMV of k_gemv.hip (whole 1-KiB row pieces per wave-load, fp32 VALU dot products, halving-butterfly row
+    sums): 7B layer shapes, rows of 1 .. 3 pieces per wave, ragged row counts, pieces past the end of a row, fp32 and fp16 outputs."""
+    test_linear(wq, M, N, K)
+
+
+@pytest.mark.parametrize("wq", [0, 8, 4])
+@pytest.mark.parametrize("M,inter,K", [(1, 11008, 4096), (2, 1376, 512), (3, 100, 128), (1, 40, 4096), (4, 3000, 11008)])
+def test_linear_streaming_gemv_swiglu(wq, M, inter, K):
+    test_linear_swiglu_fused(wq, M, inter, K)
