@@ -1136,6 +1136,17 @@ static int layer_linear(pplhip_ctx* c, int rank, const Linear& l, const uint16_t
     return 0;
 }
 
+// Small-batch decode steps (<= 4 token rows, tensor-parallel size 1, weight-only quantisation): the two RMSNorms of a layer are folded into
+// the streaming GEMVs that consume them (k_gemv.hip, GemvFuse) and the residual update they would have written is done as a side job of
+// the following row-parallel GEMV (wo: h += previous layer's FFN output; w2: h += attention output) -- 64 launches of ~4 us less per
+// 7B step.  Bit-identical to the unfused step (same arithmetic, same order) -- and MEASURED SLOWER: every one of the ~768 short blocks of a
+// GEMV pays the row reduction (an L2 round trip, a barrier) in front of its first product: batch 1 2.42 -> 2.62 ms, batch 4 3.01 -> 4.28 ms
+// (gpurun_out/small_batch_2.log, round 4).  Kept behind PPLHIP_FUSE_NORM=1 with its test; not the default.
+static bool fuse_small_step(const pplhip_ctx* c, const Linear& l, int64_t rows) {
+    static const int on = getenv("PPLHIP_FUSE_NORM") ? atoi(getenv("PPLHIP_FUSE_NORM")) : 0;  // measured slower (below): off
+    return on && c->tp == 1 && c->d.act_quant_bit != 8 && rows >= 1 && rows <= gemv_stream_max_m(l.qbit, l.group, l.N, l.Kp) && l.Kp == c->d.hidden_dim;
+}
+
 // attention block of layer l for one chunk: (Skip)RMSNorm -> wqkv -> RoPE + KV write -> attention -> wo (partial sums)
 static int layer_attention_part(pplhip_ctx* c, int rank, int l, const Chunk& k, const uint16_t* pending, int split, int threads) {
     Rank& R = c->ranks[rank];
@@ -1148,11 +1159,22 @@ static int layer_attention_part(pplhip_ctx* c, int rank, int l, const Chunk& k, 
     uint16_t* h = R.h + k.t0 * hd;
     uint16_t* xn = R.xn + k.t0 * hd;
     const bool a8 = d.act_quant_bit == 8;  // the norm writes the int8 operand of the next linear directly (no fp16 xn, no separate pass)
-    HIPCK(c, rank, launch_rmsnorm(s, h, pending ? pending + k.t0 * hd : nullptr, L.attn_norm, d.norm_eps, k.tn, hd, nullptr, xn,
-                                  pending ? h : nullptr, a8 ? R.xq : nullptr, a8 ? R.sx : nullptr));
-    prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-    { int rc = layer_linear(c, rank, L.wqkv, xn, k.tn, R.qkv + k.t0 * nqkv, L.wqkv.N, false, a8); if (rc) return rc; }
-    prof_end(R, &ev);
+    const bool fuse = fuse_small_step(c, L.wqkv, k.tn) && fuse_small_step(c, L.w13, k.tn) && k.t0 == 0;
+    if (fuse) {
+        GemvFuse f;
+        f.skip = pending;
+        f.norm_w = L.attn_norm;
+        f.eps = d.norm_eps;
+        prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
+        HIPCK(c, rank, launch_gemv_stream(s, h, L.wqkv.w, L.wqkv.scale, L.wqkv.qbit, L.wqkv.group, k.tn, L.wqkv.N, L.wqkv.Kp, R.qkv, L.wqkv.N, 0, &f));
+        prof_end(R, &ev);
+    } else {
+        HIPCK(c, rank, launch_rmsnorm(s, h, pending ? pending + k.t0 * hd : nullptr, L.attn_norm, d.norm_eps, k.tn, hd, nullptr, xn,
+                                      pending ? h : nullptr, a8 ? R.xq : nullptr, a8 ? R.sx : nullptr));
+        prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
+        { int rc = layer_linear(c, rank, L.wqkv, xn, k.tn, R.qkv + k.t0 * nqkv, L.wqkv.N, false, a8); if (rc) return rc; }
+        prof_end(R, &ev);
+    }
     const KvAddr kv = make_kv_addr(d, Hkv, D, R.kv_tokens, R.kv_cache, R.kv_scale, l);
     HIPCK(c, rank, launch_rope_kv_write(s, R.qkv, R.rope, kv, d.cache_quant_bit, d.cache_quant_group, R.d_seq, R.d_sp, R.d_ci,
                                         R.max_pages, R.B, k.t0, k.tn, H, Hkv, D));
@@ -1188,7 +1210,15 @@ static int layer_attention_part(pplhip_ctx* c, int rank, int l, const Chunk& k, 
         prof_end(R, &ev);
     }
     prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-    { int rc = layer_linear(c, rank, L.wo, R.att + k.t0 * (int64_t)H * D, k.tn, R.part + k.t0 * hd, hd, false); if (rc) return rc; }
+    if (fuse && k.tn <= gemv_stream_max_m(L.wo.qbit, L.wo.group, L.wo.N, L.wo.Kp)) {
+        GemvFuse f;   // side job: the residual update the fused attention norm skipped (h += previous layer's FFN output)
+        if (pending) { f.res_h = h; f.res_skip = pending; f.res_chunks = (int)(k.tn * hd / 8); }
+        HIPCK(c, rank, launch_gemv_stream(s, R.att, L.wo.w, L.wo.scale, L.wo.qbit, L.wo.group, k.tn, L.wo.N, L.wo.Kp, R.part, hd, 0, &f));
+    } else {
+        if (fuse && pending) HIPCK(c, rank, launch_rmsnorm(s, h, pending, L.attn_norm, d.norm_eps, k.tn, hd, nullptr, xn, h));  // (wo not on the GEMV: plain update)
+        int rc = layer_linear(c, rank, L.wo, R.att + k.t0 * (int64_t)H * D, k.tn, R.part + k.t0 * hd, hd, false);
+        if (rc) return rc;
+    }
     prof_end(R, &ev);
     return 0;
 }
@@ -1205,6 +1235,23 @@ static int layer_ffn_part(pplhip_ctx* c, int rank, int l, const Chunk& k) {
     uint16_t* xn = R.xn + k.t0 * hd;
     uint16_t* act = R.act + k.t0 * (int64_t)L.w2.Kp;
     const bool a8 = d.act_quant_bit == 8;
+    const bool fuse = fuse_small_step(c, L.wqkv, k.tn) && fuse_small_step(c, L.w13, k.tn) && k.t0 == 0 &&
+                      k.tn <= gemv_stream_max_m(L.w2.qbit, L.w2.group, L.w2.N, L.w2.Kp);
+    if (fuse) {
+        GemvFuse f;
+        f.skip = R.part;
+        f.norm_w = L.ffn_norm;
+        f.eps = d.norm_eps;
+        prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
+        HIPCK(c, rank, launch_gemv_stream(s, h, L.w13.w, L.w13.scale, L.w13.qbit, L.w13.group, k.tn, L.w13.N, L.w13.Kp, act, L.w2.Kp, 2, &f));
+        prof_end(R, &ev);
+        GemvFuse g;   // side job of w2: h += attention output
+        g.res_h = h; g.res_skip = R.part; g.res_chunks = (int)(k.tn * hd / 8);
+        prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
+        HIPCK(c, rank, launch_gemv_stream(s, act, L.w2.w, L.w2.scale, L.w2.qbit, L.w2.group, k.tn, L.w2.N, L.w2.Kp, R.part2, hd, 0, &g));
+        prof_end(R, &ev);
+        return 0;
+    }
     HIPCK(c, rank, launch_rmsnorm(s, h, R.part + k.t0 * hd, L.ffn_norm, d.norm_eps, k.tn, hd, nullptr, xn, h, a8 ? R.xq : nullptr,
                                   a8 ? R.sx : nullptr));
     prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
