@@ -207,7 +207,7 @@ constexpr int H_BN = 256, H_BM = 256, H_ST = 3;
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_w8_dma256_kernel(const uint16_t* __restrict__ x, const int8_t* __restrict__ w,
                                                              const uint16_t* __restrict__ scale, int64_t M, int N, int K,
-                                                             void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles, int gn, int gm) {
+                                                             void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles, int gn, int gm, int staged) {
     extern __shared__ __attribute__((aligned(16))) char smem256[];  // H_ST x (X 32 KiB + W 16 KiB)
     uint16_t* const Xs0 = reinterpret_cast<uint16_t*>(smem256);
     int8_t* const Wq0 = reinterpret_cast<int8_t*>(smem256 + H_ST * H_BM * G_BK * 2);
@@ -302,6 +302,56 @@ __global__ __launch_bounds__(512) void gemm_w8_dma256_kernel(const uint16_t* __r
         }
     }
 
+    if (staged && EPI != EPI_F32) {
+        // Output through LDS (the ring is idle; round 4): the MFMA layout gives a store instruction 32 bytes of 16 different rows; staged,
+        // a wave stores 512 contiguous bytes of two rows (16 bytes per lane).  On multi-round prefill GEMMs the partial-line stores of
+        // finishing blocks otherwise sit in the memory pipeline beside the running blocks' tile fetches (measured on the asm-loop
+        // kernel: w13 at M = 8192 1593 -> 1382 us, profiles/r04_gemm_asm_experiments.md).  Rows padded by 16 bytes against bank conflicts.
+        constexpr int OUTW = EPI == EPI_SWIGLU ? H_BN / 2 : H_BN, ROWB = OUTW * 2 + 16, CPR = OUTW / 8;
+        static_assert(H_BM * ROWB <= H_ST * (H_BM * G_BK * 2 + H_BN * G_BK), "the staging image fits the ring");
+        char* const stg = smem256;
+        __syncthreads();  // every wave is past its last fragment read
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int nl = wn * 32 + i * 16 + kq * 4;
+            const int nc = n0 + nl < N ? n0 + nl : 0;
+            const h4 sh = __builtin_bit_cast(h4, *reinterpret_cast<const uint2*>(scale + nc));
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float v0 = acc[i][j][0] * (float)sh[0], v1 = acc[i][j][1] * (float)sh[1], v2 = acc[i][j][2] * (float)sh[2],
+                            v3 = acc[i][j][3] * (float)sh[3];
+                char* dst = stg + (j * 16 + l15) * ROWB;
+                if constexpr (EPI == EPI_F16) {
+                    const h4 o = {to_h(v0), to_h(v1), to_h(v2), to_h(v3)};
+                    *reinterpret_cast<uint2*>(dst + nl * 2) = __builtin_bit_cast(uint2, o);
+                } else {
+                    const float g0 = round_h(v0), u0 = round_h(v1), g1 = round_h(v2), u1 = round_h(v3);
+                    const h2 o = {to_h(g0 / (1.0f + __expf(-g0)) * u0), to_h(g1 / (1.0f + __expf(-g1)) * u1)};
+                    *reinterpret_cast<uint32_t*>(dst + nl) = __builtin_bit_cast(uint32_t, o);
+                }
+            }
+        }
+        __syncthreads();
+        uint16_t* const y = reinterpret_cast<uint16_t*>(yv);
+        const int nout = EPI == EPI_SWIGLU ? N / 2 : N, c0 = EPI == EPI_SWIGLU ? n0 / 2 : n0;
+#pragma unroll 4
+        for (int c = tid; c < H_BM * CPR; c += 512) {
+            const int row = c / CPR, ch = c - row * CPR;
+            const uint4 v = *reinterpret_cast<const uint4*>(stg + row * ROWB + ch * 16);
+            const int64_t m = m0 + row;
+            const int col = c0 + ch * 8;
+            if (m < M) {
+                if (col + 8 <= nout) {
+                    *reinterpret_cast<uint4*>(y + m * ldy + col) = v;
+                } else {
+                    const uint16_t* e = reinterpret_cast<const uint16_t*>(&v);
+                    for (int k = 0; k < 8; ++k)
+                        if (col + k < nout) y[m * ldy + col + k] = e[k];
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int n = n0 + wn * 32 + i * 16 + kq * 4;
@@ -537,7 +587,9 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
             (void)hipFuncSetAttribute((const void*)gemm_w8_dma256_kernel<EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }
-#define L256(E) hipLaunchKernelGGL((gemm_w8_dma256_kernel<E>), g256, dim3(512), lds, s, x, (const int8_t*)w, scale, M, N, K, y, ldy, nt2, mt2, gn, gm)
+        static const int no_stage = getenv("PPLHIP_GEMM_DIRECT_EPILOGUE") ? 1 : 0;  // A/B runs
+        const int staged = !no_stage && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0 && (epi != EPI_SWIGLU || N % 16 == 0) ? 1 : 0;
+#define L256(E) hipLaunchKernelGGL((gemm_w8_dma256_kernel<E>), g256, dim3(512), lds, s, x, (const int8_t*)w, scale, M, N, K, y, ldy, nt2, mt2, gn, gm, staged)
         if (epi == EPI_F32) L256(EPI_F32); else if (epi == EPI_F16) L256(EPI_F16); else L256(EPI_SWIGLU);
 #undef L256
         return hipGetLastError();
