@@ -25,7 +25,7 @@ template <int MAXC>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint4* x /* may alias residual_out */, const uint4* __restrict__ skip,
                                                       const uint4* __restrict__ w, float eps, int chunks, int hidden,
                                                       const int64_t* __restrict__ gather, uint4* __restrict__ out,
-                                                      uint4* residual_out, int8_t* __restrict__ qout, float* __restrict__ sx) {
+                                                      uint4* residual_out, int8_t* __restrict__ qout, float* __restrict__ sx, SplitSlabs sl) {
     __shared__ float red[4];
     __shared__ float redq[4];
     const int64_t r = blockIdx.x;
@@ -37,9 +37,10 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint4* x /* may alia
         const int c = threadIdx.x + i * 256;
         if (c < chunks) {
             unpack8(x[src * chunks + c], v[i]);
-            if (skip) {
+            if (skip || sl.splits) {
                 float sk[8];
-                unpack8(skip[src * chunks + c], sk);
+                if (sl.splits) slab_load8(sl, src, c * 8, sk);   // the skip operand straight from the producing GEMM's split-K slabs
+                else unpack8(skip[src * chunks + c], sk);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[i][j] = round_h(v[i][j] + sk[j]);
                 if (residual_out) residual_out[r * chunks + c] = pack8(v[i]);
@@ -117,14 +118,19 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint4* x /* may alia
 
 hipError_t launch_rmsnorm(hipStream_t s, const uint16_t* x, const uint16_t* skip, const uint16_t* w, float eps,
                           int64_t rows, int hidden, const int64_t* gather_seq_starts, uint16_t* out,
-                          uint16_t* residual_out, int8_t* qout, float* sx) {
+                          uint16_t* residual_out, int8_t* qout, float* sx, const SplitSlabs* skip_slabs) {
     if (rows == 0) return hipSuccess;
     const int chunks = hidden / 8;
     if (hidden % 8 || chunks > 256 * 8) return hipErrorInvalidValue;
+    SplitSlabs sl;
+    if (skip_slabs && skip_slabs->splits > 0) {
+        sl = *skip_slabs;
+        if (sl.N != hidden) return hipErrorInvalidValue;
+    }
     dim3 g((unsigned)rows), b(256);
 #define RMS_LAUNCH(MC)                                                                                              \
     hipLaunchKernelGGL(rmsnorm_kernel<MC>, g, b, 0, s, (const uint4*)x, (const uint4*)skip, (const uint4*)w, eps,   \
-                       chunks, hidden, gather_seq_starts, (uint4*)out, (uint4*)residual_out, qout, sx)
+                       chunks, hidden, gather_seq_starts, (uint4*)out, (uint4*)residual_out, qout, sx, sl)
     if (chunks <= 256) RMS_LAUNCH(1);
     else if (chunks <= 512) RMS_LAUNCH(2);
     else if (chunks <= 1024) RMS_LAUNCH(4);

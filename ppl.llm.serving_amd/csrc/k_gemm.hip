@@ -642,7 +642,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const uint16_t* scale, int wq_bit, int group,
-                         int64_t M, int N, int K, void* y, int64_t ldy, bool out_fp32, float* ws, size_t ws_bytes, bool swiglu) {
+                         int64_t M, int N, int K, void* y, int64_t ldy, bool out_fp32, float* ws, size_t ws_bytes, bool swiglu, SplitSlabs* defer) {
+    if (defer) *defer = SplitSlabs{};
     if (M == 0) return hipSuccess;
     if (swiglu && out_fp32) return hipErrorInvalidValue;
     const int epi = swiglu ? EPI_SWIGLU : (out_fp32 ? EPI_F32 : EPI_F16);
@@ -827,6 +828,7 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
 #undef H128_L
             hipError_t e = hipGetLastError();
             if (e != hipSuccess || sp == 1) return e;
+            if (defer && epi == EPI_F16 && N % 8 == 0 && sp <= 8) { *defer = SplitSlabs{ws, sp, scale, N, M}; return e; }  // the consumer reduces
             const int64_t total = M * (N / 4);
             const unsigned rb = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
 #define RED(E) hipLaunchKernelGGL(splitk_reduce_kernel<E>, dim3(rb), dim3(256), 0, s, ws, sp, M, N, scale, y, ldy)
@@ -848,6 +850,7 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
 #undef DMA_LAUNCH
         hipError_t e = hipGetLastError();
         if (e != hipSuccess || splits == 1) return e;
+        if (defer && epi == EPI_F16 && N % 8 == 0 && splits <= 8) { *defer = SplitSlabs{ws, splits, wq_bit == 8 ? scale : nullptr, N, M}; return e; }
         const int64_t total = M * (N / 4);
         const unsigned rb = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
 #define RED(E) hipLaunchKernelGGL(splitk_reduce_kernel<E>, dim3(rb), dim3(256), 0, s, ws, splits, M, N, wq_bit == 8 ? scale : nullptr, y, ldy)

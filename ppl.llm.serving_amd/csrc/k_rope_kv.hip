@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(uint16_t* __restrict
                                                             KvAddr kv, const int64_t* __restrict__ seq_starts,
                                                             const int64_t* __restrict__ start_pos,
                                                             const int64_t* __restrict__ cache_indices, int64_t max_pages,
-                                                            int64_t B, int64_t t0, int H, int Hkv, int D) {
+                                                            int64_t B, int64_t t0, int H, int Hkv, int D, SplitSlabs sl) {
     __shared__ int64_t sh_b;
     const int64_t t = t0 + blockIdx.x;
     if (threadIdx.x == 0) {  // request of row t: last b with seq_starts[b] <= t
@@ -76,8 +76,13 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(uint16_t* __restrict
             const int head = w / bph, i0 = (w - head * bph) * 8;
             uint16_t* x = row + (int64_t)head * D;
             float a[8], bb[8], c[8], s[8], ra[8], rb[8];
-            unpack8(*reinterpret_cast<const uint4*>(x + i0), a);
-            unpack8(*reinterpret_cast<const uint4*>(x + i0 + half), bb);
+            if (sl.splits) {  // the qkv rows straight from wqkv's unreduced split-K slabs (kernels.h SplitSlabs)
+                slab_load8(sl, t, head * D + i0, a);
+                slab_load8(sl, t, head * D + i0 + half, bb);
+            } else {
+                unpack8(*reinterpret_cast<const uint4*>(x + i0), a);
+                unpack8(*reinterpret_cast<const uint4*>(x + i0 + half), bb);
+            }
             *reinterpret_cast<float4*>(c) = *reinterpret_cast<const float4*>(cs + i0);
             *reinterpret_cast<float4*>(c + 4) = *reinterpret_cast<const float4*>(cs + i0 + 4);
             *reinterpret_cast<float4*>(s) = *reinterpret_cast<const float4*>(cs + half + i0);
@@ -99,7 +104,8 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(uint16_t* __restrict
             const int wv = w - n_rope;
             const int head = wv / (D / 8), i0 = (wv - head * (D / 8)) * 8;
             float v[8];
-            unpack8(*reinterpret_cast<const uint4*>(row + (int64_t)(H + Hkv + head) * D + i0), v);
+            if (sl.splits) slab_load8(sl, t, (H + Hkv + head) * D + i0, v);
+            else unpack8(*reinterpret_cast<const uint4*>(row + (int64_t)(H + Hkv + head) * D + i0), v);
             store_group8<QBIT>(kv, 1, head, slot, i0, v);
         }
     }
@@ -108,15 +114,20 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(uint16_t* __restrict
 hipError_t launch_rope_kv_write(hipStream_t s, uint16_t* qkv, const float* cos_sin, const KvAddr& kv, int quant_bit,
                                 int quant_group, const int64_t* seq_starts, const int64_t* start_pos,
                                 const int64_t* cache_indices, int64_t max_pages, int64_t B, int64_t t0, int64_t T, int H,
-                                int Hkv, int D) {
+                                int Hkv, int D, const SplitSlabs* qkv_slabs) {
     if (T == 0) return hipSuccess;
+    SplitSlabs sl;
+    if (qkv_slabs && qkv_slabs->splits > 0) {
+        sl = *qkv_slabs;
+        if (t0 != 0 || sl.N != (H + 2 * Hkv) * D) return hipErrorInvalidValue;
+    }
     if (D % 16 || (quant_bit == 8 && quant_group != 8) || (quant_bit != 0 && quant_bit != 8)) return hipErrorInvalidValue;
     if (quant_bit == 8)
         hipLaunchKernelGGL(rope_kv_write_kernel<8>, dim3((unsigned)T), dim3(256), 0, s, qkv, cos_sin, kv, seq_starts,
-                           start_pos, cache_indices, max_pages, B, t0, H, Hkv, D);
+                           start_pos, cache_indices, max_pages, B, t0, H, Hkv, D, sl);
     else
         hipLaunchKernelGGL(rope_kv_write_kernel<0>, dim3((unsigned)T), dim3(256), 0, s, qkv, cos_sin, kv, seq_starts,
-                           start_pos, cache_indices, max_pages, B, t0, H, Hkv, D);
+                           start_pos, cache_indices, max_pages, B, t0, H, Hkv, D, sl);
     return hipGetLastError();
 }
 

@@ -7,6 +7,49 @@
 
 namespace pplhip {
 
+// A split-K GEMM result that has NOT been reduced yet: y[m][n] = fp16( (sum_z ws[(z M + m) N + n]) * scale[n] ) (scale NULL: 1).  The tile
+// kernels hand it to the kernel that consumes y anyway -- (Skip)RMSNorm for wo / w2, RoPE + KV write for wqkv -- instead of launching
+// splitk_reduce_kernel: one ~5 us kernel and one kernel boundary less per linear of a small-batch step (round 4).  Same arithmetic, same
+// summation order, same fp16 rounding as the reduce kernel: bit-identical results.
+struct SplitSlabs {
+    const float* ws = nullptr;
+    int splits = 0;              // 0: nothing deferred (y was written)
+    const uint16_t* scale = nullptr;
+    int N = 0;
+    int64_t M = 0;
+};
+#ifdef __HIPCC__
+// 8 consecutive outputs n .. n + 7 of row m, as fp16-rounded floats
+__device__ __forceinline__ void slab_load8(const SplitSlabs& sl, int64_t m, int n, float* o) {
+    // every slab's 32 bytes are requested before the first sum (one memory latency, not `splits` of them: a consumer row is one
+    // workgroup); slabs past `splits` re-read slab 0 and are not added.  Summation order z = 0, 1, ... like splitk_reduce_kernel.
+    const float* p = sl.ws + m * sl.N + n;
+    const int64_t zs = sl.M * sl.N;
+    float4 c[8], d[8];
+#pragma unroll
+    for (int z = 0; z < 8; ++z) {
+        const float* q = p + (z < sl.splits ? z : 0) * zs;
+        c[z] = *reinterpret_cast<const float4*>(q);
+        d[z] = *reinterpret_cast<const float4*>(q + 4);
+    }
+    float4 a = c[0], b = d[0];
+#pragma unroll
+    for (int z = 1; z < 8; ++z) {
+        if (z < sl.splits) {
+            a.x += c[z].x; a.y += c[z].y; a.z += c[z].z; a.w += c[z].w;
+            b.x += d[z].x; b.y += d[z].y; b.z += d[z].z; b.w += d[z].w;
+        }
+    }
+    if (sl.scale) {
+        const h8 sh = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(sl.scale + n));
+        a.x *= (float)sh[0]; a.y *= (float)sh[1]; a.z *= (float)sh[2]; a.w *= (float)sh[3];
+        b.x *= (float)sh[4]; b.y *= (float)sh[5]; b.z *= (float)sh[6]; b.w *= (float)sh[7];
+    }
+    o[0] = round_h(a.x); o[1] = round_h(a.y); o[2] = round_h(a.z); o[3] = round_h(a.w);
+    o[4] = round_h(b.x); o[5] = round_h(b.y); o[6] = round_h(b.z); o[7] = round_h(b.w);
+}
+#endif
+
 // ---- k_elem.hip -------------------------------------------------------------------------------
 hipError_t launch_embedding(hipStream_t s, const int64_t* token_ids, const uint16_t* table, int64_t T, int hidden,
                             uint16_t* out);
@@ -14,14 +57,16 @@ hipError_t launch_embedding(hipStream_t s, const int64_t* token_ids, const uint1
 // (last-token gather of K11), else src(r) = r.  residual_out (optional) receives fp16(x + skip) at row r.
 hipError_t launch_rmsnorm(hipStream_t s, const uint16_t* x, const uint16_t* skip, const uint16_t* w, float eps,
                           int64_t rows, int hidden, const int64_t* gather_seq_starts, uint16_t* out,
-                          uint16_t* residual_out, int8_t* qout = nullptr, float* sx = nullptr);
+                          uint16_t* residual_out, int8_t* qout = nullptr, float* sx = nullptr,
+                          const SplitSlabs* skip_slabs = nullptr);  // skip_slabs: the skip operand as unreduced split-K slabs
 hipError_t launch_silu_mul(hipStream_t s, const uint16_t* gate_up, int64_t T, int inter, uint16_t* out);
 
 // ---- k_rope_kv.hip ----------------------------------------------------------------------------
 hipError_t launch_rope_kv_write(hipStream_t s, uint16_t* qkv, const float* cos_sin, const KvAddr& kv, int quant_bit,
                                 int quant_group, const int64_t* seq_starts, const int64_t* start_pos,
                                 const int64_t* cache_indices, int64_t max_pages, int64_t B, int64_t t0, int64_t T, int H,
-                                int Hkv, int D);  // token rows [t0, t0 + T) of the step's B requests
+                                int Hkv, int D, const SplitSlabs* qkv_slabs = nullptr);  // token rows [t0, t0 + T) of the step's B requests;
+                                                   // qkv_slabs: the rows come from unreduced split-K slabs (t0 must be 0); rotated q -> qkv
 
 // ---- k_attn_decode.hip ------------------------------------------------------------------------
 // rows [0, nb) of the batch are single-token queries; q row of request b is qkv row seq_starts[b].
@@ -69,7 +114,7 @@ hipError_t launch_linear_w8_asm(hipStream_t s, const uint16_t* x, const int8_t* 
 int linear_w8_wide_waves(int64_t M, int N);  // 12 when the 128 x 384 tiles fill rounds of 256 blocks well enough, else 0
 hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const uint16_t* scale, int wq_bit, int group,
                          int64_t M, int N, int K, void* y, int64_t ldy, bool out_fp32, float* ws = nullptr, size_t ws_bytes = 0,
-                         bool swiglu = false);
+                         bool swiglu = false, SplitSlabs* defer = nullptr);  // defer: a split-K launch leaves its slabs unreduced there
 // ---- k_gemv.hip: streaming GEMV, 1 <= M <= 4 (whole 1-KiB row pieces per wave-load; VALU dot products) ----------------------------
 int gemv_stream_max_m(int wq_bit, int group, int N, int K);  // largest M the kernel takes for this shape (0: none)
 // optional fusions of a small-batch decode step (tensor-parallel size 1):

@@ -85,6 +85,10 @@ struct Rank {
     uint64_t pages_cap = 0;
     int64_t B = 0, T = 0, decoding_batches = 0, max_seq_len = 0, max_kv_len = 0, max_pages = 0;
     int64_t total_kv = 0;  // kv_starts[B]: sum of the requests' kv lengths of this step
+    // split-K results left unreduced for the kernel that consumes them (kernels.h SplitSlabs): wqkv -> RoPE + KV write, wo -> FFN norm,
+    // w2 -> the next layer's attention norm (or the final norm)
+    SplitSlabs sl_qkv, sl_part, sl_part2;
+    bool defer_reduce = false;   // this step: tensor-parallel size 1, weight-only quantisation, no residual dump
 
     // activations
     uint16_t *h = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *part = nullptr, *part2 = nullptr, *gu = nullptr,
@@ -1127,14 +1131,15 @@ struct Chunk {
 // per token first and multiplied in int8.  x rows have stride l.Kp.
 // pre_quantised: R.xq / R.sx already hold the rows (written by the RMSNorm in front of wqkv / w13).
 static int layer_linear(pplhip_ctx* c, int rank, const Linear& l, const uint16_t* x, int64_t M, void* y, int64_t ldy, bool swiglu,
-                        bool pre_quantised = false) {
+                        bool pre_quantised = false, SplitSlabs* defer = nullptr) {
     Rank& R = c->ranks[rank];
     if (c->d.act_quant_bit == 8) {
         if (!pre_quantised) HIPCK(c, rank, launch_quant_act(R.stream, x, M, l.Kp, l.Kp, R.xq, l.Kp, R.sx));
         HIPCK(c, rank, launch_linear_i8(R.stream, R.xq, R.sx, (const int8_t*)l.w, l.scale, M, l.N, l.Kp, y, ldy, false, swiglu));
         return 0;
     }
-    HIPCK(c, rank, launch_linear(R.stream, x, l.w, l.scale, l.qbit, l.group, M, l.N, l.Kp, y, ldy, false, R.gemm_ws, R.gemm_ws_bytes, swiglu));
+    HIPCK(c, rank, launch_linear(R.stream, x, l.w, l.scale, l.qbit, l.group, M, l.N, l.Kp, y, ldy, false, R.gemm_ws, R.gemm_ws_bytes, swiglu,
+                                 R.defer_reduce ? defer : nullptr));
     return 0;
 }
 
@@ -1172,14 +1177,16 @@ static int layer_attention_part(pplhip_ctx* c, int rank, int l, const Chunk& k, 
         prof_end(R, &ev);
     } else {
         HIPCK(c, rank, launch_rmsnorm(s, h, pending ? pending + k.t0 * hd : nullptr, L.attn_norm, d.norm_eps, k.tn, hd, nullptr, xn,
-                                      pending ? h : nullptr, a8 ? R.xq : nullptr, a8 ? R.sx : nullptr));
+                                      pending ? h : nullptr, a8 ? R.xq : nullptr, a8 ? R.sx : nullptr, pending ? &R.sl_part2 : nullptr));
+        R.sl_part2 = SplitSlabs{};
         prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-        { int rc = layer_linear(c, rank, L.wqkv, xn, k.tn, R.qkv + k.t0 * nqkv, L.wqkv.N, false, a8); if (rc) return rc; }
+        { int rc = layer_linear(c, rank, L.wqkv, xn, k.tn, R.qkv + k.t0 * nqkv, L.wqkv.N, false, a8, &R.sl_qkv); if (rc) return rc; }
         prof_end(R, &ev);
     }
     const KvAddr kv = make_kv_addr(d, Hkv, D, R.kv_tokens, R.kv_cache, R.kv_scale, l);
     HIPCK(c, rank, launch_rope_kv_write(s, R.qkv, R.rope, kv, d.cache_quant_bit, d.cache_quant_group, R.d_seq, R.d_sp, R.d_ci,
-                                        R.max_pages, R.B, k.t0, k.tn, H, Hkv, D));
+                                        R.max_pages, R.B, k.t0, k.tn, H, Hkv, D, &R.sl_qkv));
+    R.sl_qkv = SplitSlabs{};
     // decode rows of the chunk: per-request arrays shifted to the chunk (q rows stay absolute through seq_starts);
     // prefill requests: absolute request range
     const int64_t ci_stride = d.cache_mode == 1 ? R.max_pages : 1;
@@ -1218,7 +1225,7 @@ static int layer_attention_part(pplhip_ctx* c, int rank, int l, const Chunk& k, 
         HIPCK(c, rank, launch_gemv_stream(s, R.att, L.wo.w, L.wo.scale, L.wo.qbit, L.wo.group, k.tn, L.wo.N, L.wo.Kp, R.part, hd, 0, &f));
     } else {
         if (fuse && pending) HIPCK(c, rank, launch_rmsnorm(s, h, pending, L.attn_norm, d.norm_eps, k.tn, hd, nullptr, xn, h));  // (wo not on the GEMV: plain update)
-        int rc = layer_linear(c, rank, L.wo, R.att + k.t0 * (int64_t)H * D, k.tn, R.part + k.t0 * hd, hd, false);
+        int rc = layer_linear(c, rank, L.wo, R.att + k.t0 * (int64_t)H * D, k.tn, R.part + k.t0 * hd, hd, false, false, &R.sl_part);
         if (rc) return rc;
     }
     prof_end(R, &ev);
@@ -1255,12 +1262,13 @@ static int layer_ffn_part(pplhip_ctx* c, int rank, int l, const Chunk& k) {
         return 0;
     }
     HIPCK(c, rank, launch_rmsnorm(s, h, R.part + k.t0 * hd, L.ffn_norm, d.norm_eps, k.tn, hd, nullptr, xn, h, a8 ? R.xq : nullptr,
-                                  a8 ? R.sx : nullptr));
+                                  a8 ? R.sx : nullptr, &R.sl_part));
+    R.sl_part = SplitSlabs{};
     prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
     { int rc = layer_linear(c, rank, L.w13, xn, k.tn, act, L.w2.Kp, /*swiglu=*/true, a8); if (rc) return rc; }
     prof_end(R, &ev);
     prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-    { int rc = layer_linear(c, rank, L.w2, act, k.tn, R.part2 + k.t0 * hd, hd, false); if (rc) return rc; }
+    { int rc = layer_linear(c, rank, L.w2, act, k.tn, R.part2 + k.t0 * hd, hd, false, false, &R.sl_part2); if (rc) return rc; }
     prof_end(R, &ev);
     return 0;
 }
@@ -1352,6 +1360,9 @@ static int run_launches(pplhip_ctx* c, int rank) {
     int split[2] = {1, 1};
     for (int i = 0; i < nck; ++i) split[i] = ck[i].nd > 0 ? decode_split(c, ck[i].nd, R.max_kv_len) : 1;
 
+    static const int defer_on = getenv("PPLHIP_DEFER_REDUCE") ? atoi(getenv("PPLHIP_DEFER_REDUCE")) : 1;
+    R.defer_reduce = defer_on && !comm && d.act_quant_bit != 8 && !R.dump_dev && nck == 1;
+    R.sl_qkv = R.sl_part = R.sl_part2 = SplitSlabs{};
     ProfEvent ev_run, ev;
     prof_begin(c, R, PPLHIP_PROF_RUN, &ev_run);
     HIPCK(c, rank, launch_embedding(s, R.d_tok, R.embed, T, hd, R.h));
@@ -1380,7 +1391,8 @@ static int run_launches(pplhip_ctx* c, int rank) {
     if (ov && !tpdbg2) for (int i = 0; i < nck; ++i) if ((rc = wait_reduced(c, rank, i))) return rc;
     // K11: last-token gather + final (Skip)RMSNorm (the last FFN output is folded into the residual of the gathered
     // rows only) + lm_head (+ all-gather of the vocab shards)
-    HIPCK(c, rank, launch_rmsnorm(s, R.h, pending, R.norm, d.norm_eps, B, hd, R.d_seq, R.hn, nullptr));
+    HIPCK(c, rank, launch_rmsnorm(s, R.h, pending, R.norm, d.norm_eps, B, hd, R.d_seq, R.hn, nullptr, nullptr, nullptr, pending ? &R.sl_part2 : nullptr));
+    R.sl_part2 = SplitSlabs{};
     prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
     if (!comm) {
         HIPCK(c, rank, launch_linear(s, R.hn, R.output.w, nullptr, 0, 0, B, R.output.N, hd, R.logits, d.vocab_size, true, R.gemm_ws, R.gemm_ws_bytes));

@@ -405,3 +405,46 @@ def test_small_batch_decode_with_norms_fused_into_the_streaming_gemv(wq, kvq, ba
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         unfused = np.load(out)
     assert (logits.view(np.uint32) == unfused.view(np.uint32)).all(), float(np.abs(logits - unfused).max())
+
+
+def _defer_case_logits(wq, kvq, batch, steps=3):
+    m = load_pplhip()
+    desc = ref.make_desc(hidden_dim=2048, intermediate_dim=5632, num_layers=2, num_heads=16, num_kv_heads=16, vocab_size=1024,
+                         max_position=512, cache_quant_bit=kvq, cache_quant_group=8 if kvq else 1, cache_layout=3,
+                         cache_mode=0, weight_quant_bit=wq, weight_quant_group=128)
+    rm = ref.RefModel(desc)
+    rm.init_synthetic(31)
+    ctx = m.Context(m.copy_desc(desc), max_running_batch=256, max_tokens_per_step=1024)
+    ctx.init_synthetic(0, 31)
+    ntok = batch * 16 + 64
+    rm.kv_alloc(ntok)
+    ctx.kv_alloc(0, ntok)
+    rng = np.random.RandomState(batch)
+    prompts = [rng.randint(3, 1024, size=int(n)) for n in rng.randint(1, 9, size=batch)]
+    res = generate_both(m, ctx, [rm], desc, prompts, steps, ntok)
+    ctx.close()
+    rm.close()
+    return res
+
+
+@pytest.mark.parametrize("wq,kvq,batch", [(8, 8, 6), (8, 8, 40), (0, 0, 24), (8, 0, 200), (4, 8, 12), (8, 8, 130)])
+def test_split_k_slabs_reduced_by_the_consuming_kernel(wq, kvq, batch):
+    """tensor-parallel size 1, 4 < M <= 256: the split-K slabs of wqkv / wo / w2 are summed by RoPE + KV write and by the (Skip)RMSNorms
+    that consume them instead of a reduce kernel of their own (kernels.h SplitSlabs) -- against the oracle, and BIT-identical to the
+    same steps with PPLHIP_DEFER_REDUCE=0 (child process: the switch is read once)."""
+    import subprocess, sys
+    res = _defer_case_logits(wq, kvq, batch)
+    check_steps(res, k=3)   # (this geometry's noise floor: 1.2e-3)
+    logits = np.stack([r[0] for r in res])
+    code = ("import sys, numpy as np\n"
+            "from tests.test_gpu_model import _defer_case_logits\n"
+            f"res = _defer_case_logits({wq}, {kvq}, {batch})\n"
+            "np.save(sys.argv[1], np.stack([r[0] for r in res]))\n")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "plain.npy")
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, PPLHIP_DEFER_REDUCE="0"), cwd=root, capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        plain = np.load(out)
+    assert (logits.view(np.uint32) == plain.view(np.uint32)).all(), float(np.abs(logits - plain).max())
