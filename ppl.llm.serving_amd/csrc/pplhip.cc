@@ -286,7 +286,9 @@ int decode_split(const pplhip_ctx* c, int64_t nb, int64_t max_kv_len) {
     // launch costs more than the second block per CU brings, profiles/r03_roofline_sweep.json)
     if (mode == 2 || (blocks < 256 && max_kv_len >= 512)) {
         int64_t want = (512 + blocks - 1) / blocks;            // aim for >= 512 workgroups
-        int64_t cap = std::max<int64_t>(1, max_kv_len / 256);  // >= 256 tokens per split
+        // >= 256 tokens per split; >= 128 when there are very few blocks (batch 1-4 of a multi-head model: kv 512 split 4 8.6 us against 10.3 us
+        // with split 2, kv 2048 split 8 11.0 against 13.8 with 4 -- one memory round trip per wave instead of two, round 4)
+        int64_t cap = std::max<int64_t>(1, blocks <= 128 ? std::min<int64_t>(max_kv_len / 128, 8) : max_kv_len / 256);
         split = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want, cap), 32));
         if (mode == 2 && split < 2 && max_kv_len >= 64) split = 2;
     }
