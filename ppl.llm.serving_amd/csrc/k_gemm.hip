@@ -204,62 +204,70 @@ __global__ __launch_bounds__(WL == 6 ? 768 : (WL == 5 ? 512 : 256)) void gemm_dm
 // is [128 rows][128 B] (two 64-deep sub-tiles side by side, chunk-swizzled like an activation tile), the activation stage two
 // [64 rows][64 fp16] sub-tiles; 4 waves of 32 (n) x 64 (m), 32 MFMAs per wave and stage, split-K slabs + the common reduce kernel.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int S_BM = 64, S_KS = 2;                                  // activation rows, 64-deep sub-tiles per stage
-constexpr int S_XB = S_KS * S_BM * G_BK * 2, S_WB = G_BN * G_BK * S_KS;  // 16 KiB + 16 KiB per stage
+// Round 4, second step: the activation sub-tile is as tall as the batch needs (BM = 16 / 32 / 64 rows), so that the LDS a block does not
+// spend on padding rows holds more stages of the weight stream: what bounds these steps is weight bytes in flight per CU (32 KiB with two
+// 64-row blocks of two stages; 64 KiB with three stages of a 16- or 32-row block, two blocks per CU).
+constexpr int S_KS = 2;                                             // 64-deep sub-tiles per stage
+constexpr int S_WB = G_BN * G_BK * S_KS;                            // weight bytes per stage: 16 KiB
+template <int BM> constexpr int s_xb() { return S_KS * BM * G_BK * 2; }  // activation bytes per stage: 4 / 8 / 16 KiB
 
-template <int EPI, int ST>
+template <int EPI, int ST, int BM>
 __global__ __launch_bounds__(256) void gemm_w8_half128_kernel(const uint16_t* __restrict__ x, const int8_t* __restrict__ w,
                                                               const uint16_t* __restrict__ scale, int64_t M, int N, int K,
                                                               void* __restrict__ yv, int64_t ldy, int n_tiles, int kt_per_split,
                                                               float* __restrict__ ws) {
+    constexpr int XB = s_xb<BM>(), NJ = BM / 16;
+    constexpr int XP = XB / 1024, WP = S_WB / 1024, PP = (XP + WP) / 4;   // 1-KiB DMA pieces per stage: X, W, per wave (5 / 6 / 8)
+    static_assert((XP + WP) % 4 == 0, "every wave issues the same number of pieces");
     extern __shared__ __attribute__((aligned(16))) char smem_h[];  // ST x X, then ST x W
     char* const Xs0 = smem_h;
-    char* const Wq0 = smem_h + ST * S_XB;
-    const int id = blockIdx.x;
-    const int nt = id;                       // (M <= 64: one activation tile; XCD id % 8 streams the weight tiles n == id (mod 8))
+    char* const Wq0 = smem_h + ST * XB;
+    const int nt = blockIdx.x;               // (one activation tile; XCD id % 8 streams the weight tiles n == id (mod 8))
     if (nt >= n_tiles) return;
     const int n0 = nt * G_BN;
     const int split_id = blockIdx.y, n_splits = gridDim.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
     const int nb = wave * 32;
 
-    // per-lane DMA sources.  X sub-tile u, piece j (2 per sub-tile): rows 32 j + (tid >> 3), chunk as in gemm_dma_body (the k permutation
-    // that lets ONE 16-byte read of an int8 row serve both k-steps of a lane); W piece j (4): rows 32 j + (tid >> 3), chunk (tid & 7) ^ swz
-    const uint16_t* xsrc[2];
-    const int8_t* wsrc[4];
+    // piece P = wave + 4 j of a stage.  P < XP: activation sub-tile u = P / (BM / 8), rows 8 (P % (BM / 8)) .. + 8, chunk permutation of
+    // gemm_dma_body (ONE 16-byte read of an int8 row then serves both k-steps of a lane); else weight rows 8 (P - XP) .. + 8, 128 B each
+    const char* psrc[PP];
+    uint32_t pdst[PP];
+    const uint32_t xbase = lds_addr(Xs0), wbase = lds_addr(Wq0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int p = j * 256 + tid, row = p >> 3, pos = (p & 7) ^ ((row >> 1) & 7);
-        const int c = ((pos & 3) << 1) | (pos >> 2);
-        int64_t m = row;
-        if (m >= M) m = M - 1;
-        xsrc[j] = x + m * K + c * 8;
+    for (int j = 0; j < PP; ++j) {
+        const int P = wave + 4 * j;
+        if (P < XP) {
+            const int u = P / (BM / 8), q = P % (BM / 8);
+            const int row = q * 8 + (lane >> 3), pos = (lane & 7) ^ ((row >> 1) & 7);
+            const int c = ((pos & 3) << 1) | (pos >> 2);
+            int64_t m = row;
+            if (m >= M) m = M - 1;
+            psrc[j] = reinterpret_cast<const char*>(x + m * K + u * G_BK + c * 8);
+            pdst[j] = __builtin_amdgcn_readfirstlane(xbase + P * 1024);
+        } else {
+            const int row = (P - XP) * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+            int n = n0 + row;
+            if (n >= N) n = N - 1;
+            psrc[j] = reinterpret_cast<const char*>(w) + (int64_t)n * K + c * 16;
+            pdst[j] = __builtin_amdgcn_readfirstlane(wbase + (P - XP) * 1024);
+        }
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int p = j * 256 + tid, row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
-        int n = n0 + row;
-        if (n >= N) n = N - 1;
-        wsrc[j] = w + (int64_t)n * K + c * 16;
-    }
-    const uint32_t xdst = __builtin_amdgcn_readfirstlane(lds_addr(Xs0) + wave * 1024);
-    const uint32_t wdst = __builtin_amdgcn_readfirstlane(lds_addr(Wq0) + wave * 1024);
     auto issue = [&](int stage, int k0) {
 #pragma unroll
-        for (int u = 0; u < S_KS; ++u)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) glds16(xsrc[j] + k0 + u * G_BK, xdst + stage * S_XB + u * (S_BM * G_BK * 2) + j * 4096);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(wsrc[j] + k0, wdst + stage * S_WB + j * 4096);
+        for (int j = 0; j < PP; ++j) {
+            const bool isx = wave + 4 * j < XP;   // (wave-uniform)
+            glds16(psrc[j] + (isx ? (int64_t)k0 * 2 : (int64_t)k0), pdst[j] + stage * (isx ? XB : S_WB));
+        }
     };
-    constexpr int PT = 2 * S_KS + 4, D = ST - 1;
+    constexpr int D = ST - 1;
 
-    f4 acc[2][4];
+    f4 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
     const int kt_all = K / (G_BK * S_KS);
     const int kt0 = split_id * kt_per_split;
     const int ktiles = (kt0 + kt_per_split < kt_all) ? kt_per_split : kt_all - kt0;
@@ -269,18 +277,18 @@ __global__ __launch_bounds__(256) void gemm_w8_half128_kernel(const uint16_t* __
     int st = 0, stn = D % ST;
     for (int t = 0; t < ktiles; ++t) {
         const int younger = (ktiles - 1 - t) < (D - 1) ? (ktiles - 1 - t) : (D - 1);
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PT) : "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PT) : "memory");
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PP) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + D < ktiles) issue(stn, (kt0 + t + D) * (G_BK * S_KS));
-        const char* xs0 = Xs0 + st * S_XB;
+        const char* xs0 = Xs0 + st * XB;
         const char* wq = Wq0 + st * S_WB;
         st = st == ST - 1 ? 0 : st + 1;
         stn = stn == ST - 1 ? 0 : stn + 1;
 #pragma unroll
         for (int u = 0; u < S_KS; ++u) {
-            const uint16_t* xs = reinterpret_cast<const uint16_t*>(xs0 + u * (S_BM * G_BK * 2));
+            const uint16_t* xs = reinterpret_cast<const uint16_t*>(xs0 + u * (BM * G_BK * 2));
             uint4 wraw[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -289,18 +297,18 @@ __global__ __launch_bounds__(256) void gemm_w8_half128_kernel(const uint16_t* __
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                h8 a[2], bfr[4];
+                h8 a[2], bfr[NJ];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) a[i] = cvt_i8x8_f16(ks == 0 ? make_uint2(wraw[i].x, wraw[i].y) : make_uint2(wraw[i].z, wraw[i].w));
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     const int row = j * 16 + l15;
                     bfr[j] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&xs[row * G_BK + g_swz(row, ks * 4 + kq) * 8]));
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], bfr[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], bfr[j], acc[i][j], 0, 0, 0);
             }
         }
     }
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(256) void gemm_w8_half128_kernel(const uint16_t* __
             const int n = n0 + nb + i * 16 + kq * 4;
             if (n >= N) continue;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int64_t m = j * 16 + l15;
                 if (m < M) *reinterpret_cast<float4*>(slab + m * N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
             }
@@ -324,7 +332,7 @@ __global__ __launch_bounds__(256) void gemm_w8_half128_kernel(const uint16_t* __
         if (n >= N) continue;
         const h4 sh = __builtin_bit_cast(h4, *reinterpret_cast<const uint2*>(scale + n));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int64_t m = j * 16 + l15;
             if (m >= M) continue;
             store4<EPI>(yv, ldy, m, n, acc[i][j][0] * (float)sh[0], acc[i][j][1] * (float)sh[1], acc[i][j][2] * (float)sh[2],
@@ -801,28 +809,32 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         if (half) wl = 1;
         // W8, one block per CU: eight consumer waves, each group multiplying one of the two k-steps of a tile (w2 at M = 1024: 100 -> 96 us)
         if ((forced_wl == 6 || (forced_wl == 0 && wl == 5)) && wq_bit == 8 && stages >= 3 && splits == 1) wl = 6;
-        // W8, half-height tiles: the 128-deep K tile (whole 128-byte lines of every weight row per LDS-DMA piece; gemm_w8_half128_kernel)
-        static const int half128 = getenv("PPLHIP_GEMM_HALF128") ? atoi(getenv("PPLHIP_GEMM_HALF128")) : 1;
+        // W8, half-height tiles: the 128-deep K tile (whole 128-byte lines of every weight row per LDS-DMA piece; gemm_w8_half128_kernel),
+        // activation sub-tile 16 / 32 / 64 rows; three stages when two blocks of them fit a CU (BM <= 32) or the grid is one block per CU
+        static const int half128 = getenv("PPLHIP_GEMM_HALF128") ? atoi(getenv("PPLHIP_GEMM_HALF128")) : 1;  // 0: off; 2: always 64-row sub-tiles
         if (half128 && half && wq_bit == 8 && K % (G_BK * S_KS) == 0) {
             const int kt128 = K / (G_BK * S_KS);
             int sp = splits;
             if (sp > kt128) sp = kt128;
             const int kt_per128 = (kt128 + sp - 1) / sp;
             sp = (kt128 + kt_per128 - 1) / kt_per128;
-            const int st = (int64_t)n_tiles * sp <= 256 ? 3 : 2;
-            const size_t lds = (size_t)st * (S_XB + S_WB);
+            const int bm = half128 == 2 ? 64 : (M <= 16 ? 16 : (M <= 32 ? 32 : 64));
+            const int st = (bm <= 32 || (int64_t)n_tiles * sp <= 256) ? 3 : 2;
+            const size_t lds = (size_t)st * ((bm == 16 ? s_xb<16>() : bm == 32 ? s_xb<32>() : s_xb<64>()) + S_WB);
             static bool attr_dev[64] = {false};
             int dev = 0;
             (void)hipGetDevice(&dev);
             if (!attr_dev[dev & 63]) {
-#define H128_A(E, S) (void)hipFuncSetAttribute((const void*)gemm_w8_half128_kernel<E, S>, hipFuncAttributeMaxDynamicSharedMemorySize, S * (S_XB + S_WB))
-                H128_A(EPI_F16, 2); H128_A(EPI_F16, 3); H128_A(EPI_F32, 2); H128_A(EPI_F32, 3); H128_A(EPI_SWIGLU, 2); H128_A(EPI_SWIGLU, 3);
+#define H128_A(E, S, B) (void)hipFuncSetAttribute((const void*)gemm_w8_half128_kernel<E, S, B>, hipFuncAttributeMaxDynamicSharedMemorySize, S * (s_xb<B>() + S_WB))
+#define H128_AE(E) H128_A(E, 3, 16); H128_A(E, 3, 32); H128_A(E, 2, 64); H128_A(E, 3, 64)
+                H128_AE(EPI_F16); H128_AE(EPI_F32); H128_AE(EPI_SWIGLU);
+#undef H128_AE
 #undef H128_A
                 attr_dev[dev & 63] = true;
             }
             dim3 gh((unsigned)n_tiles, (unsigned)sp);
-#define H128_L(E, S) hipLaunchKernelGGL((gemm_w8_half128_kernel<E, S>), gh, dim3(256), lds, s, x, (const int8_t*)w, scale, M, N, K, y, ldy, n_tiles, kt_per128, ws)
-#define H128_E(E) do { if (st == 3) H128_L(E, 3); else H128_L(E, 2); } while (0)
+#define H128_L(E, S, B) hipLaunchKernelGGL((gemm_w8_half128_kernel<E, S, B>), gh, dim3(256), lds, s, x, (const int8_t*)w, scale, M, N, K, y, ldy, n_tiles, kt_per128, ws)
+#define H128_E(E) do { if (bm == 16) H128_L(E, 3, 16); else if (bm == 32) H128_L(E, 3, 32); else if (st == 3) H128_L(E, 3, 64); else H128_L(E, 2, 64); } while (0)
             if (epi == EPI_F32) H128_E(EPI_F32); else if (epi == EPI_F16) H128_E(EPI_F16); else H128_E(EPI_SWIGLU);
 #undef H128_E
 #undef H128_L

@@ -83,9 +83,9 @@ def traffic_table(fetch_db, write_db, out_json, model, batch, kv_len, layers, to
     for i in range(min(n, total_steps)):
         fs, ws = f[i * layers:(i + 1) * layers], w[i * layers:(i + 1) * layers]
         table[str(kv_len + i + 1)] = int(2 * 1024 * sum(fs) / len(fs) + 1024 * sum(ws) / len(ws))
-    out = {"round": 3, "kernel": "pplhip::attn_decode_kernel<8,128>", "label": label, "model": model, "batch": batch, "kv_quant": 8,
+    out = {"round": int(label.split()[-1]) if label.split()[-1].isdigit() else 0, "kernel": "pplhip::attn_decode_kernel<8,128>", "label": label, "model": model, "batch": batch, "kv_quant": 8,
            "cache_mode": 0, "dispatches": {"FETCH_SIZE": len(f), "WRITE_SIZE": len(w)}, "layers": layers,
-           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only; profiles/collect_r03.sh) of "
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only; profiles/collect_r04.sh) of "
                      "`python bench.py --steps 24 --warmup 3` -- a superset of the driver's --steps 20 --warmup 5 and of the defaults",
            "source_short": f"profiles/attn_decode_traffic.json ({label}; PMC FETCH_SIZE x2 + WRITE_SIZE per dispatch, mean per kv length)",
            "correction": "gfx950: FETCH_SIZE counts a 128-B request as 64 B for wide (16 B/lane) coalesced reads, so it is doubled "
