@@ -521,7 +521,9 @@ def main():
             tf = flops / (gemm_ms_per_step * 1e-3) / 1e12
             res["roofline_gemm"] = {"kernel": "gemm_w8_wide_kernel (128x384x64, wqkv / w13) + gemm_dma_kernel (128x128x64, wo / w2), LDS-DMA rings", "bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0,
                                     "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "flops_per_step": flops,
-                                    "note": "dense fp16 MFMA peak; durations from the bracketed extra steps (breakdown_ms_per_step.gemm)"}
+                                    "note": "dense fp16 MFMA peak; durations from the bracketed extra steps (breakdown_ms_per_step.gemm).  On these operands (random fp16 x "
+                                            "int8) the K loops sit on the chip's power limit: ~1.25 PFLOP/s in-loop for the compiler-scheduled and the hand-scheduled kernel "
+                                            "alike, 1.96 PFLOP/s for the same hand-scheduled binary on zero operands (profiles/r04_gemm_asm_experiments.md)"}
         res.update(extra)
         if ragged is not None:
             res["ragged_batch"] = ragged
