@@ -523,7 +523,7 @@ def main():
                                     "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "flops_per_step": flops,
                                     "note": "dense fp16 MFMA peak; durations from the bracketed extra steps (breakdown_ms_per_step.gemm).  On these operands (random fp16 x "
                                             "int8) the K loops sit on the chip's power limit: ~1.25 PFLOP/s in-loop for the compiler-scheduled and the hand-scheduled kernel "
-                                            "alike, 1.96 PFLOP/s for the same hand-scheduled binary on zero operands (profiles/r04_gemm_asm_experiments.md)"}
+                                            "alike, 1.96 PFLOP/s for the same hand-scheduled binary on zero operands; a bare MFMA stream reaches 1.73 PFLOP/s on such operands (2.49 on zeros): profiles/r04_gemm_asm_experiments.md"}
         res.update(extra)
         if ragged is not None:
             res["ragged_batch"] = ragged
