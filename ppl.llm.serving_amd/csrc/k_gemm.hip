@@ -649,6 +649,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+hipError_t launch_splitk_reduce(hipStream_t s, const float* ws, int splits, int64_t M, int N, const uint16_t* scale, void* y, int64_t ldy, int epi) {
+    const int64_t total = M * (N / 4);
+    if (total == 0) return hipSuccess;
+    const unsigned rb = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
+#define RED(E) hipLaunchKernelGGL(splitk_reduce_kernel<E>, dim3(rb), dim3(256), 0, s, ws, splits, M, N, scale, y, ldy)
+    if (epi == EPI_F32) RED(EPI_F32); else if (epi == EPI_F16) RED(EPI_F16); else RED(EPI_SWIGLU);
+#undef RED
+    return hipGetLastError();
+}
+
 hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const uint16_t* scale, int wq_bit, int group,
                          int64_t M, int N, int K, void* y, int64_t ldy, bool out_fp32, float* ws, size_t ws_bytes, bool swiglu, SplitSlabs* defer) {
     if (defer) *defer = SplitSlabs{};
@@ -814,7 +824,18 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         static const int half128 = getenv("PPLHIP_GEMM_HALF128") ? atoi(getenv("PPLHIP_GEMM_HALF128")) : 1;  // 0: off; 2: always 64-row sub-tiles
         if (half128 && half && wq_bit == 8 && K % (G_BK * S_KS) == 0) {
             const int kt128 = K / (G_BK * S_KS);
+            // split-K slabs: ONE block per CU, not three.  A slab costs 8 M N bytes (written here, read by the reduce or the consuming
+            // kernel) against N K / splits weight bytes -- at M = 64 and K / splits = 683 that is 0.75 extra bytes per weight byte, and it
+            // is written when all blocks finish together.  Measured on the 7B shapes, HBM-cold (profiles/r04_splitk_sweep.log): w13 at
+            // M = 64 with 5 / 1 slabs 37.6 / 29.9 us (and no reduce kernel), wqkv 6 / 2 slabs 25.1 / 20.7 us; wo / w2 (32 tiles) keep 8
+            static const int h_blocks = getenv("PPLHIP_GEMM_HALF128_BLOCKS") ? atoi(getenv("PPLHIP_GEMM_HALF128_BLOCKS")) : 256;
             int sp = splits;
+            if (ws && forced_split <= 0) {
+                sp = h_blocks / n_tiles;
+                if (sp > 8) sp = 8;
+                if (sp < 1) sp = 1;
+                while (sp > 1 && (size_t)sp * M * N * sizeof(float) > ws_bytes) --sp;
+            }
             if (sp > kt128) sp = kt128;
             const int kt_per128 = (kt128 + sp - 1) / sp;
             sp = (kt128 + kt_per128 - 1) / kt_per128;
