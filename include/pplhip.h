@@ -296,16 +296,6 @@ PPLHIP_API int pplhip_op_linear(void* stream, const void* x, const void* w, cons
 PPLHIP_API int pplhip_op_linear_swiglu(void* stream, const void* x, const void* w, const void* scale, int32_t wq_bit,
                                        int32_t group, int64_t M, int32_t N, int32_t K, void* y);
 
-/* W8A16 at 4 < M <= 256 on FRAGMENT-MAJOR weights: a second copy of an int8 [N,K] matrix (K % 128 == 0) in the order the matrix unit
- * reads its operand (csrc/k_gemm_frag.hip), made once at load time; the linear then streams it straight into registers.
- * pplhip_weight_frag_bytes: size of the copy; pplhip_weight_pack_frag: fills it from the row-major matrix;
- * pplhip_op_linear_frag: y = x . W^T * scale with epi 0 (fp16 [M,N]) / 1 (fp32 [M,N]) / 2 (fused SwiGLU, fp16 [M,N/2], rows interleaved
- * as for pplhip_op_linear_swiglu).  The runtime keeps such copies itself when PPLHIP_FRAG_WEIGHTS is on. */
-PPLHIP_API int64_t pplhip_weight_frag_bytes(int32_t N, int32_t K);
-PPLHIP_API int pplhip_weight_pack_frag(void* stream, const void* w, int32_t N, int32_t K, void* out);
-PPLHIP_API int pplhip_op_linear_frag(void* stream, const void* x, const void* wfrag, const void* scale, int64_t M, int32_t N, int32_t K,
-                                     void* y, int32_t epi);
-
 /* online_i8i8 (W8A8, src/backends/cuda/resource_manager.cc:51-52).  Per-token activation quantisation: q[M,K] int8,
  * sx[M] = max|x| / 127; per-output-row weight quantisation of an fp16 [N,K] matrix: q[N,K] int8, scale[N] fp16;
  * y[m,n] = (sum_k xq * w as int32) * sx[m] * scale[n], rounded to fp16 (or kept fp32); swiglu as in pplhip_op_linear_swiglu. */

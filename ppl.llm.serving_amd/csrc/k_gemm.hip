@@ -862,12 +862,7 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
             hipError_t e = hipGetLastError();
             if (e != hipSuccess || sp == 1) return e;
             if (defer && epi == EPI_F16 && N % 8 == 0 && sp <= 8) { *defer = SplitSlabs{ws, sp, scale, N, M}; return e; }  // the consumer reduces
-            const int64_t total = M * (N / 4);
-            const unsigned rb = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
-#define RED(E) hipLaunchKernelGGL(splitk_reduce_kernel<E>, dim3(rb), dim3(256), 0, s, ws, sp, M, N, scale, y, ldy)
-            if (epi == EPI_F32) RED(EPI_F32); else if (epi == EPI_F16) RED(EPI_F16); else RED(EPI_SWIGLU);
-#undef RED
-            return hipGetLastError();
+            return launch_splitk_reduce(s, ws, sp, M, N, scale, y, ldy, epi);
         }
 #define DMA_LAUNCH(WQ, O32, ST)                                                                                     \
     do { if constexpr (WQ == 8 && ST >= 3) { if (wl == 6) { hipLaunchKernelGGL((gemm_dma_kernel<WQ, O32, ST, 6>), g2, dim3(768), 0, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles, map_mode, kt_per, ws); break; } } \
@@ -884,12 +879,7 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         hipError_t e = hipGetLastError();
         if (e != hipSuccess || splits == 1) return e;
         if (defer && epi == EPI_F16 && N % 8 == 0 && splits <= 8) { *defer = SplitSlabs{ws, splits, wq_bit == 8 ? scale : nullptr, N, M}; return e; }
-        const int64_t total = M * (N / 4);
-        const unsigned rb = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
-#define RED(E) hipLaunchKernelGGL(splitk_reduce_kernel<E>, dim3(rb), dim3(256), 0, s, ws, splits, M, N, wq_bit == 8 ? scale : nullptr, y, ldy)
-        if (epi == EPI_F32) RED(EPI_F32); else if (epi == EPI_F16) RED(EPI_F16); else RED(EPI_SWIGLU);
-#undef RED
-        return hipGetLastError();
+        return launch_splitk_reduce(s, ws, splits, M, N, wq_bit == 8 ? scale : nullptr, y, ldy, epi);
     }
 #define GEMM_CASE(WQ, O32)                                                                                          \
     if (wq_bit == WQ && epi == (int)O32) {                                                                          \

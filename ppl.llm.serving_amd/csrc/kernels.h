@@ -117,12 +117,6 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
                          bool swiglu = false, SplitSlabs* defer = nullptr);  // defer: a split-K launch leaves its slabs unreduced there
 // y = (sum of `splits` fp32 slabs [M][N] at ws) * scale (NULL: 1), epilogue epi (0 fp16 / 1 fp32 / 2 fused SwiGLU)
 hipError_t launch_splitk_reduce(hipStream_t s, const float* ws, int splits, int64_t M, int N, const uint16_t* scale, void* y, int64_t ldy, int epi);
-// ---- k_gemm_frag.hip: W8A16 at 4 < M <= 256 on fragment-major weights (a second, load-time copy of the matrix) ------------------------
-size_t w8_frag_bytes(int N, int K);                                                        // bytes of the fragment-major copy
-hipError_t launch_pack_w8_frag(hipStream_t s, const int8_t* w, int N, int K, void* out);   // W [N][K] int8 row-major -> fragment-major
-bool linear_w8_frag_supported(int64_t M, int N, int K);
-hipError_t launch_linear_w8_frag(hipStream_t s, const uint16_t* x, const void* wfrag, const uint16_t* scale, int64_t M, int N, int K, void* y,
-                                 int64_t ldy, int epi, float* ws, size_t ws_bytes, SplitSlabs* defer = nullptr);
 // ---- k_gemv.hip: streaming GEMV, 1 <= M <= 4 (whole 1-KiB row pieces per wave-load; VALU dot products) ----------------------------
 int gemv_stream_max_m(int wq_bit, int group, int N, int K);  // largest M the kernel takes for this shape (0: none)
 // optional fusions of a small-batch decode step (tensor-parallel size 1):

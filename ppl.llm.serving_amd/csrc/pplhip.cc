@@ -1720,21 +1720,6 @@ int pplhip_op_linear_swiglu(void* stream, const void* x, const void* w, const vo
                                false, ws, ws_bytes, true));
 }
 
-int64_t pplhip_weight_frag_bytes(int32_t N, int32_t K) { return (int64_t)w8_frag_bytes(N, K); }
-
-int pplhip_weight_pack_frag(void* stream, const void* w, int32_t N, int32_t K, void* out) {
-    return op_rc(launch_pack_w8_frag((hipStream_t)stream, (const int8_t*)w, N, K, out));
-}
-
-int pplhip_op_linear_frag(void* stream, const void* x, const void* wfrag, const void* scale, int64_t M, int32_t N, int32_t K, void* y,
-                          int32_t epi) {
-    if (epi < 0 || epi > 2) return PPLHIP_INVALID_VALUE;
-    size_t ws_bytes = 0;
-    float* ws = op_linear_ws(&ws_bytes);
-    return op_rc(launch_linear_w8_frag((hipStream_t)stream, (const uint16_t*)x, wfrag, (const uint16_t*)scale, M, N, K, y, epi == 2 ? N / 2 : N,
-                                       epi, ws, ws_bytes));
-}
-
 int pplhip_op_rmsnorm_quant(void* stream, const void* x, const void* skip, const void* w, float eps, int64_t T, int32_t hidden,
                             void* residual_out, void* q, float* sx) {
     return op_rc(launch_rmsnorm((hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)skip, (const uint16_t*)w, eps, T, hidden, nullptr,

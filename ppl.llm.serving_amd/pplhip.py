@@ -77,7 +77,7 @@ SYMBOLS = [
     "pplhip_kv_block_bytes", "pplhip_kv_capacity", "pplhip_kv_alloc", "pplhip_kv_ptrs", "pplhip_kv_read",
     "pplhip_kv_write", "pplhip_kv_fill_synthetic", "pplhip_set_inputs", "pplhip_run", "pplhip_debug_run_dump", "pplhip_logits", "pplhip_copy_logits", "pplhip_sync",
     "pplhip_sample", "pplhip_penalty", "pplhip_profile_reset", "pplhip_profile_get", "pplhip_profile_mode", "pplhip_mem_info",
-    "pplhip_op_embedding", "pplhip_op_rmsnorm", "pplhip_op_linear", "pplhip_op_linear_swiglu", "pplhip_weight_frag_bytes", "pplhip_weight_pack_frag", "pplhip_op_linear_frag", "pplhip_op_rmsnorm_quant", "pplhip_op_quant_act", "pplhip_op_quant_weight",
+    "pplhip_op_embedding", "pplhip_op_rmsnorm", "pplhip_op_linear", "pplhip_op_linear_swiglu", "pplhip_op_rmsnorm_quant", "pplhip_op_quant_act", "pplhip_op_quant_weight",
     "pplhip_op_linear_i8", "pplhip_op_silu_mul", "pplhip_op_rope_kv_write",
     "pplhip_op_attention", "pplhip_build_rope_table",
 ]
@@ -129,10 +129,6 @@ def lib():
         L.pplhip_op_rmsnorm.argtypes = [vp, vp, vp, vp, f32, i64, i32, vp, vp]
         L.pplhip_op_linear.argtypes = [vp, vp, vp, vp, i32, i32, i64, i32, i32, vp, i32]
         L.pplhip_op_linear_swiglu.argtypes = [vp, vp, vp, vp, i32, i32, i64, i32, i32, vp]
-        L.pplhip_weight_frag_bytes.argtypes = [i32, i32]
-        L.pplhip_weight_frag_bytes.restype = i64
-        L.pplhip_weight_pack_frag.argtypes = [vp, vp, i32, i32, vp]
-        L.pplhip_op_linear_frag.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, i32]
         L.pplhip_op_rmsnorm_quant.argtypes = [vp, vp, vp, vp, C.c_float, i64, i32, vp, vp, vp]
         L.pplhip_op_quant_act.argtypes = [vp, vp, i64, i32, vp, vp]
         L.pplhip_op_quant_weight.argtypes = [vp, vp, i32, i32, vp, vp]
