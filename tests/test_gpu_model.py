@@ -448,3 +448,47 @@ def test_split_k_slabs_reduced_by_the_consuming_kernel(wq, kvq, batch):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         plain = np.load(out)
     assert (logits.view(np.uint32) == plain.view(np.uint32)).all(), float(np.abs(logits - plain).max())
+
+
+def _long_kv_case_logits(kvq, nreq, steps=5):
+    m = load_pplhip()
+    desc = ref.make_desc(hidden_dim=512, intermediate_dim=1408, num_layers=2, num_heads=4, num_kv_heads=4, vocab_size=1024,
+                         max_position=1024, cache_quant_bit=kvq, cache_quant_group=8 if kvq else 1, cache_layout=3,
+                         cache_mode=0, weight_quant_bit=8, weight_quant_group=128)
+    rm = ref.RefModel(desc)
+    rm.init_synthetic(57)
+    ctx = m.Context(m.copy_desc(desc), max_running_batch=16, max_tokens_per_step=4096)
+    ctx.init_synthetic(0, 57)
+    lens = [515, 701, 530, 644, 519, 770][:nreq]
+    ntok = sum(lens) + nreq * (steps + 2) + 64
+    rm.kv_alloc(ntok)
+    ctx.kv_alloc(0, ntok)
+    rng = np.random.RandomState(nreq)
+    prompts = [rng.randint(3, 1024, size=n) for n in lens]
+    res = generate_both(m, ctx, [rm], desc, prompts, steps, ntok)
+    ctx.close()
+    rm.close()
+    return res
+
+
+@pytest.mark.parametrize("kvq,nreq", [(8, 1), (8, 3), (0, 6)])
+def test_decode_k_splits_merged_by_the_last_block(kvq, nreq):
+    """a few decode rows over > 512 cached tokens: the runtime splits the keys of every (request, head) over 4-8 blocks, and the block that
+    arrives last merges the partial rows in the same launch (k_attn_decode_dev.h; counters that return to zero, five steps in a row) --
+    against the oracle, and BIT-identical to the same steps with the separate reduce kernel (PPLHIP_ATTN_FUSED_MERGE=0, child process)."""
+    import subprocess, sys
+    res = _long_kv_case_logits(kvq, nreq)
+    check_steps(res, k=2)
+    logits = np.stack([r[0] for r in res])
+    code = ("import sys, numpy as np\n"
+            "from tests.test_gpu_model import _long_kv_case_logits\n"
+            f"res = _long_kv_case_logits({kvq}, {nreq})\n"
+            "np.save(sys.argv[1], np.stack([r[0] for r in res]))\n")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "plain.npy")
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, PPLHIP_ATTN_FUSED_MERGE="0"), cwd=root, capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        plain = np.load(out)
+    assert (logits.view(np.uint32) == plain.view(np.uint32)).all(), float(np.abs(logits - plain).max())
