@@ -472,23 +472,9 @@ def _long_kv_case_logits(kvq, nreq, steps=5):
 
 
 @pytest.mark.parametrize("kvq,nreq", [(8, 1), (8, 3), (0, 6)])
-def test_decode_k_splits_merged_by_the_last_block(kvq, nreq):
-    """a few decode rows over > 512 cached tokens: the runtime splits the keys of every (request, head) over 4-8 blocks, and the block that
-    arrives last merges the partial rows in the same launch (k_attn_decode_dev.h; counters that return to zero, five steps in a row) --
-    against the oracle, and BIT-identical to the same steps with the separate reduce kernel (PPLHIP_ATTN_FUSED_MERGE=0, child process)."""
-    import subprocess, sys
-    res = _long_kv_case_logits(kvq, nreq)
-    check_steps(res, k=2)
-    logits = np.stack([r[0] for r in res])
-    code = ("import sys, numpy as np\n"
-            "from tests.test_gpu_model import _long_kv_case_logits\n"
-            f"res = _long_kv_case_logits({kvq}, {nreq})\n"
-            "np.save(sys.argv[1], np.stack([r[0] for r in res]))\n")
-    with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "plain.npy")
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, PPLHIP_ATTN_FUSED_MERGE="0"), cwd=root, capture_output=True,
-                           text=True, timeout=900)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-        plain = np.load(out)
-    assert (logits.view(np.uint32) == plain.view(np.uint32)).all(), float(np.abs(logits - plain).max())
+def test_decode_rows_over_long_histories_with_k_splits(kvq, nreq):
+    """a few decode rows over 515-770 cached tokens: the runtime splits the keys of every (request, head) over 4-8 blocks + the merge
+    kernel (pplhip.cc decode_split), five steps in a row, against the oracle.  (Round 4 measured merging the partial rows in the same
+    launch -- last block to arrive at a per-(request, head) counter -- bit-identical and SLOWER: batch 1 / 2 / 4 2.37 / 2.57 / 3.00 ->
+    2.62 / 3.17 / 4.20 ms; the device-scope release / acquire every block then needs costs more than the ~4 us launch it saves.)"""
+    check_steps(_long_kv_case_logits(kvq, nreq), k=2)
