@@ -25,10 +25,10 @@ template <int QBIT, int D>
 __global__ void attn_decode_kernel(const uint16_t* __restrict__ qkv, KvAddr kv, const int64_t* __restrict__ seq_starts,
                                    const int64_t* __restrict__ start_pos, const int64_t* __restrict__ cache_indices,
                                    int64_t max_pages, int H, int Hkv, int split, float* __restrict__ workspace,
-                                   uint16_t* __restrict__ out, uint32_t* __restrict__ counters) {
+                                   uint16_t* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [NW][D + 2]
     attn_decode_body<QBIT, D>(qkv, kv, seq_starts, start_pos, cache_indices, max_pages, H, Hkv, split, workspace, out, (int)blockIdx.x,
-                              (int64_t)blockIdx.y, (int)blockIdx.z, (int)(blockDim.x >> 6), smem, counters);
+                              (int64_t)blockIdx.y, (int)blockIdx.z, (int)(blockDim.x >> 6), smem);
 }
 
 // split-K reduce: one wave per (request, head)
@@ -57,20 +57,20 @@ template <int QBIT, int D>
 static hipError_t launch_decode_t(hipStream_t s, const uint16_t* qkv, const KvAddr& kv, const int64_t* seq_starts,
                                   const int64_t* start_pos, const int64_t* cache_indices, int64_t max_pages, int64_t nb,
                                   int H, int Hkv, int split, int threads, float* workspace, uint16_t* out, hipEvent_t t0,
-                                  hipEvent_t t1, uint32_t* counters) {
+                                  hipEvent_t t1) {
     const int nw = threads / 64;
     const size_t lds = (size_t)nw * (D + 2) * sizeof(float);
     // t0 / t1: start and stop timestamps taken from the kernel's own dispatch packet -- no extra barrier packets on the stream
     // (an hipEventRecord pair around the launch costs ~10 us of GPU time)
     if (t0 && t1)
         hipExtLaunchKernelGGL((attn_decode_kernel<QBIT, D>), dim3(H, (unsigned)nb, split), dim3(threads), lds, s, t0, t1, 0, qkv, kv,
-                              seq_starts, start_pos, cache_indices, max_pages, H, Hkv, split, workspace, out, counters);
+                              seq_starts, start_pos, cache_indices, max_pages, H, Hkv, split, workspace, out);
     else
         hipLaunchKernelGGL((attn_decode_kernel<QBIT, D>), dim3(H, (unsigned)nb, split), dim3(threads), lds, s, qkv, kv,
-                           seq_starts, start_pos, cache_indices, max_pages, H, Hkv, split, workspace, out, counters);
+                           seq_starts, start_pos, cache_indices, max_pages, H, Hkv, split, workspace, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (split > 1 && !counters) {   // (with counters the last block of every (request, head) has merged the rows)
+    if (split > 1) {
         hipLaunchKernelGGL((attn_decode_reduce_kernel<D>), dim3((unsigned)(nb * H)), dim3(D < 64 ? 64 : D), 0, s,
                            workspace, split, out);
         e = hipGetLastError();
@@ -81,7 +81,7 @@ static hipError_t launch_decode_t(hipStream_t s, const uint16_t* qkv, const KvAd
 hipError_t launch_attn_decode(hipStream_t s, const uint16_t* qkv, const KvAddr& kv, int quant_bit,
                               const int64_t* seq_starts, const int64_t* start_pos, const int64_t* cache_indices,
                               int64_t max_pages, int64_t nb, int H, int Hkv, int D, int64_t max_kv_len, int split,
-                              int threads, float* workspace, uint16_t* out, hipEvent_t t0, hipEvent_t t1, uint32_t* split_counters) {
+                              int threads, float* workspace, uint16_t* out, hipEvent_t t0, hipEvent_t t1) {
     if (nb == 0) return hipSuccess;
     static const int forced_tpb = getenv("PPLHIP_ATTN_TPB") ? atoi(getenv("PPLHIP_ATTN_TPB")) : 0;  // tuning only
     if (forced_tpb) threads = forced_tpb;
@@ -103,7 +103,7 @@ hipError_t launch_attn_decode(hipStream_t s, const uint16_t* qkv, const KvAddr& 
 #define DEC_CASE(QB, DD)                                                                                            \
     if (quant_bit == QB && D == DD)                                                                                 \
         return launch_decode_t<QB, DD>(s, qkv, kv, seq_starts, start_pos, cache_indices, max_pages, nb, H, Hkv,     \
-                                       split, threads, workspace, out, t0, t1, split_counters);
+                                       split, threads, workspace, out, t0, t1);
     DEC_CASE(8, 128) DEC_CASE(0, 128) DEC_CASE(8, 64) DEC_CASE(0, 64) DEC_CASE(8, 32) DEC_CASE(0, 32)
 #undef DEC_CASE
     return hipErrorInvalidValue;

@@ -23,8 +23,7 @@ template <int QBIT, int D>
 __device__ __forceinline__ void attn_decode_body(const uint16_t* __restrict__ qkv, const KvAddr& kv, const int64_t* __restrict__ seq_starts,
                                                  const int64_t* __restrict__ start_pos, const int64_t* __restrict__ cache_indices,
                                                  int64_t max_pages, int H, int Hkv, int split, float* __restrict__ workspace,
-                                                 uint16_t* __restrict__ out, int hq, int64_t b, int sp, int nw, float* smem,
-                                                 uint32_t* __restrict__ counters = nullptr) {
+                                                 uint16_t* __restrict__ out, int hq, int64_t b, int sp, int nw, float* smem) {
     using C = DecodeCfg<QBIT, D>;
     constexpr int CH = C::CH, LPT = C::LPT, TPW = C::TPW;
     // smem: [nw][D + 2] floats, provided by the caller
@@ -239,37 +238,6 @@ __device__ __forceinline__ void attn_decode_body(const uint16_t* __restrict__ qk
             float* ws = workspace + ((b * H + hq) * (int64_t)split + sp) * (D + 2);
             ws[d] = o;
             if (d == 0) { ws[D] = mm; ws[D + 1] = ll; }
-        }
-    }
-    // K-split, merged in the same launch (round 4): the block that arrives LAST at the (request, head) counter merges the partial rows --
-    // in split order, with the arithmetic of attn_decode_reduce_kernel, so the result does not depend on which block that is -- and
-    // leaves the counter at zero for the next launch.  One ~4 us kernel less per layer of a small-batch step.
-    if (split > 1 && counters) {
-        __threadfence();   // release this thread's part of the partial row at device scope (the XCDs' L2s are not coherent by themselves)
-        __syncthreads();
-        uint32_t* flag = reinterpret_cast<uint32_t*>(smem);
-        if (threadIdx.x == 0) {
-            uint32_t* cnt = counters + (b * H + hq);
-            const uint32_t seen = atomicAdd(cnt, 1u);
-            *flag = seen == (uint32_t)split - 1 ? 1u : 0u;
-            if (seen == (uint32_t)split - 1) *cnt = 0;   // (the next launch is ordered behind this one)
-        }
-        __syncthreads();
-        if (*flag) {
-            __threadfence();   // acquire the other blocks' rows
-            if (threadIdx.x < D) {
-                const int d = threadIdx.x;
-                const volatile float* ws = workspace + (b * H + hq) * (int64_t)split * (D + 2);
-                float mm = -1e30f;
-                for (int s = 0; s < split; ++s) mm = fmaxf(mm, ws[s * (D + 2) + D]);
-                float ll = 0.f, o = 0.f;
-                for (int s = 0; s < split; ++s) {
-                    const float a = __expf(ws[s * (D + 2) + D] - mm);
-                    ll = fmaf(ws[s * (D + 2) + D + 1], a, ll);
-                    o = fmaf(ws[s * (D + 2) + d], a, o);
-                }
-                out[(b * H + hq) * (int64_t)D + d] = f2h(o / ll);
-            }
         }
     }
 }

@@ -75,9 +75,7 @@ size_t attn_decode_workspace_bytes(int64_t nb, int H, int D, int split);
 hipError_t launch_attn_decode(hipStream_t s, const uint16_t* qkv, const KvAddr& kv, int quant_bit,
                               const int64_t* seq_starts, const int64_t* start_pos, const int64_t* cache_indices,
                               int64_t max_pages, int64_t nb, int H, int Hkv, int D, int64_t max_kv_len, int split,
-                              int threads, float* workspace, uint16_t* out, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr,
-                              uint32_t* split_counters = nullptr);  // split_counters: nb * H zeroed words that stay with the caller between launches -- the
-                                                                    // multi-head kernel then merges its K-splits itself (no reduce launch)
+                              int threads, float* workspace, uint16_t* out, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 
 // ---- k_attn_prefill.hip -----------------------------------------------------------------------
 // requests [b0, B): causal attention of their new tokens over the cache [0, start_pos + seqlen).

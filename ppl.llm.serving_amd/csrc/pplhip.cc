@@ -102,7 +102,6 @@ struct Rank {
     float* logits = nullptr;        // [B, V]
     float* attn_ws = nullptr;
     size_t attn_ws_bytes = 0;
-    uint32_t* attn_counters = nullptr;  // [cap_B * H] arrival counters of the decode kernel's K-splits (zero between launches)
     float* gemm_ws = nullptr;  // split-K partial slabs
     size_t gemm_ws_bytes = 0;
 
@@ -716,8 +715,6 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
         ALLOC(R.logits, (uint64_t)cap_B * d.vocab_size * 4);
         R.attn_ws_bytes = attn_decode_workspace_bytes(cap_B, c->H, c->D, 32);
         ALLOC(R.attn_ws, R.attn_ws_bytes);
-        ALLOC(R.attn_counters, (uint64_t)cap_B * c->H * 4);
-        HIPCK(cp, r, hipMemset(R.attn_counters, 0, (uint64_t)cap_B * c->H * 4));
         R.gemm_ws_bytes = (size_t)8 * 256 * (size_t)std::max(std::max(2 * c->inter, (c->H + 2 * c->Hkv) * c->D), std::max(hd, c->vocab_local)) * sizeof(float);
         R.gemm_ws_bytes = std::max<size_t>(R.gemm_ws_bytes, (size_t)96 << 20);
         ALLOC(R.gemm_ws, R.gemm_ws_bytes);
@@ -1196,8 +1193,6 @@ static int layer_attention_part(pplhip_ctx* c, int rank, int l, const Chunk& k, 
     // prefill requests: absolute request range
     const int64_t ci_stride = d.cache_mode == 1 ? R.max_pages : 1;
     if (k.nd > 0) {
-        static const int fused_merge = getenv("PPLHIP_ATTN_FUSED_MERGE") ? atoi(getenv("PPLHIP_ATTN_FUSED_MERGE")) : 1;
-        uint32_t* split_counters = fused_merge ? R.attn_counters : nullptr;
         if (c->o.enable_profiling == 2) {
             // light profiling: the launch carries its own start / stop events (timestamps of the dispatch packet, no barrier
             // packets on the stream; with split-K the reduce kernel is not included)
@@ -1207,13 +1202,13 @@ static int layer_attention_part(pplhip_ctx* c, int rank, int l, const Chunk& k, 
             ev.cls = PPLHIP_PROF_ATTN_DECODE; ev.a = p.first; ev.b = p.second;
             HIPCK(c, rank, launch_attn_decode(s, R.qkv, kv, d.cache_quant_bit, R.d_seq + k.b0, R.d_sp + k.b0, R.d_ci + k.b0 * ci_stride,
                                               R.max_pages, k.nd, H, Hkv, D, R.max_kv_len, split, threads, R.attn_ws,
-                                              R.att + k.b0 * (int64_t)H * D, ev.a, ev.b, split_counters));
+                                              R.att + k.b0 * (int64_t)H * D, ev.a, ev.b));
             R.prof.push_back(ev);
         } else {
             prof_begin(c, R, PPLHIP_PROF_ATTN_DECODE, &ev);
             HIPCK(c, rank, launch_attn_decode(s, R.qkv, kv, d.cache_quant_bit, R.d_seq + k.b0, R.d_sp + k.b0, R.d_ci + k.b0 * ci_stride,
                                               R.max_pages, k.nd, H, Hkv, D, R.max_kv_len, split, threads, R.attn_ws,
-                                              R.att + k.b0 * (int64_t)H * D, nullptr, nullptr, split_counters));
+                                              R.att + k.b0 * (int64_t)H * D));
             prof_end(R, &ev);
         }
     }
