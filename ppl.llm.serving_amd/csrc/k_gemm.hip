@@ -753,6 +753,9 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
     // W4: group 128 = two K tiles; one block keeps at most W4_MAXG groups of scales in LDS
     const bool w4_fast = wq_bit == 4 && group == 128 && K % 128 == 0 &&
                          (K / 128 <= W4_MAXG || (ws && (size_t)((K / 128 + W4_MAXG - 1) / W4_MAXG) * M * N * sizeof(float) <= ws_bytes));
+    // (Round 4, measured and removed: W4 at 128 < M <= 256 as ONE 256-row tile per weight tile -- 4 waves of 32 (n) x 256 (m), every int4
+    // fragment converted once for 16 MFMAs instead of 8 -- is SLOWER on the 70B / TP8 shapes: w13 49.1 -> 53.4 us, w2 31.5 -> 38.9 us at
+    // M = 256; 236 VGPRs and 88 KiB of LDS leave one wave per SIMD.  profiles/r04_w4_m256_sweep.log)
     if ((wq_bit == 8 || wq_bit == 0 || w4_fast) && K % G_BK == 0 && !force_generic) {
         static const int forced = getenv("PPLHIP_GEMM_MAP") ? atoi(getenv("PPLHIP_GEMM_MAP")) : -1;
         // measured (profiles/gemm_microbench.py, M = 1024): weight tiles per XCD (mode 0) beats activation slices per XCD

@@ -1,5 +1,5 @@
 // K4 + K5 fused: rotary position embedding on q and k of the fused qkv rows, then write of k, v into the KV
-// slab -- with int8 group-8 quantisation when cache_quant_bit == 8.  HBM-bound, one workgroup per token.
+// slab -- with int8 group-8 quantisation when cache_quant_bit == 8.  HBM-bound; 1-4 workgroups per token.
 //
 // Work item = one (head, 8-channel block) of a token:
 //   q / k heads: channels [i0, i0+8) and their RoPE partners [i0+D/2, i0+D/2+8) (half-split pairing) -- two
@@ -7,6 +7,7 @@
 //   v heads    : channels [i0, i0+8), copy / quantise only.
 // Position of row t of request b: start_pos[b] + (t - seq_starts[b]) (src/generator/llm_generator.cc:263-298);
 // slot of (b, pos): kv_slot() (k_common.h).  Oracle: ref_rope_kv_write (oracle/llama_ref.c).
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace pplhip {
@@ -44,11 +45,12 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(uint16_t* __restrict
                                                             const int64_t* __restrict__ start_pos,
                                                             const int64_t* __restrict__ cache_indices, int64_t max_pages,
                                                             int64_t B, int64_t t0, int H, int Hkv, int D, SplitSlabs sl) {
-    __shared__ int64_t sh_b;
     const int64_t t = t0 + blockIdx.x;
-    if (threadIdx.x == 0) {  // request of row t: last b with seq_starts[b] <= t
-        // decode rows come first and have one token each, so row t usually IS request t: two independent loads instead
-        // of a chain of log2(B) dependent ones in front of every block
+    // request of row t: last b with seq_starts[b] <= t.  Every thread finds it for itself (wave-uniform loads that hit L2): no LDS
+    // broadcast and no barrier in front of the row's own loads, which depend on t alone and are issued beside this chain.  Decode rows
+    // come first and have one token each, so row t usually IS request t: two independent loads instead of log2(B) dependent ones
+    int64_t b;
+    {
         const int64_t g = t < B ? t : B - 1;
         int64_t lo = 0, hi = B - 1;
         if (seq_starts[g] <= t && t < seq_starts[g + 1]) {
@@ -59,10 +61,8 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(uint16_t* __restrict
                 if (seq_starts[mid] <= t) lo = mid; else hi = mid - 1;
             }
         }
-        sh_b = lo;
+        b = lo;
     }
-    __syncthreads();
-    const int64_t b = sh_b;
     const int64_t pos = start_pos[b] + (t - seq_starts[b]);
     const int64_t slot = kv_slot(kv, cache_indices, max_pages, b, pos);
     const int half = D / 2;
@@ -71,7 +71,9 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(uint16_t* __restrict
     const int n_v = Hkv * (D / 8);
     uint16_t* row = qkv + t * (int64_t)(H + 2 * Hkv) * D;
     const float* cs = cos_sin + pos * D;       // cos[0..half) then sin[0..half)
-    for (int w = threadIdx.x; w < n_rope + n_v; w += 256) {
+    // gridDim.y blocks share a token's work items (one item per thread at the LLaMA geometries: the step is a chain of dependent
+    // latencies, not bandwidth -- 7B, 128 rows: 11.8 -> see DESIGN.md)
+    for (int w = blockIdx.y * 256 + threadIdx.x; w < n_rope + n_v; w += 256 * gridDim.y) {
         if (w < n_rope) {
             const int head = w / bph, i0 = (w - head * bph) * 8;
             uint16_t* x = row + (int64_t)head * D;
@@ -122,11 +124,18 @@ hipError_t launch_rope_kv_write(hipStream_t s, uint16_t* qkv, const float* cos_s
         if (t0 != 0 || sl.N != (H + 2 * Hkv) * D) return hipErrorInvalidValue;
     }
     if (D % 16 || (quant_bit == 8 && quant_group != 8) || (quant_bit != 0 && quant_bit != 8)) return hipErrorInvalidValue;
+    const int items = (H + Hkv) * (D / 16) + Hkv * (D / 8);
+    static const int forced_y = getenv("PPLHIP_ROPE_BLOCKS_PER_TOKEN") ? atoi(getenv("PPLHIP_ROPE_BLOCKS_PER_TOKEN")) : 0;
+    int gy = (items + 255) / 256;            // one item per thread ...
+    if (gy > 4) gy = 4;
+    if (T >= 4096 && gy > 2) gy = 2;         // ... unless the launch fills the chip many times over anyway
+    if (forced_y > 0) gy = forced_y;
+    const dim3 grid((unsigned)T, (unsigned)gy);
     if (quant_bit == 8)
-        hipLaunchKernelGGL(rope_kv_write_kernel<8>, dim3((unsigned)T), dim3(256), 0, s, qkv, cos_sin, kv, seq_starts,
+        hipLaunchKernelGGL(rope_kv_write_kernel<8>, grid, dim3(256), 0, s, qkv, cos_sin, kv, seq_starts,
                            start_pos, cache_indices, max_pages, B, t0, H, Hkv, D, sl);
     else
-        hipLaunchKernelGGL(rope_kv_write_kernel<0>, dim3((unsigned)T), dim3(256), 0, s, qkv, cos_sin, kv, seq_starts,
+        hipLaunchKernelGGL(rope_kv_write_kernel<0>, grid, dim3(256), 0, s, qkv, cos_sin, kv, seq_starts,
                            start_pos, cache_indices, max_pages, B, t0, H, Hkv, D, sl);
     return hipGetLastError();
 }
