@@ -690,7 +690,9 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
     if (M <= gemv_stream_max_m(wq_bit, group, N, K) && !no_skinny && !force_generic)
         return launch_gemv_stream(s, x, w, scale, wq_bit, group, M, N, K, y, ldy, epi);
     // (without a split-K workspace the half-height tiles would run as N / 128 unsplit blocks: the skinny kernel keeps its 16 rows there)
-    if (M <= (ws && ws_bytes ? gemv_max_m : 16) && M <= 16 && !no_skinny) {
+    // (int8 weights with K % 128 == 0: from 3 rows the half-height tiles with 16-row activation sub-tiles are faster than either GEMV)
+    const int skinny_max = wq_bit == 8 && K % (G_BK * 2) == 0 && gemv_max_m > 2 && !getenv("PPLHIP_GEMV_MAX_M") ? 2 : gemv_max_m;
+    if (M <= (ws && ws_bytes ? skinny_max : 16) && M <= 16 && !no_skinny) {
 #define GEMV_DISPATCH(WQ)                                                                                      \
     if (wq_bit == WQ)                                                                                          \
         return epi == EPI_F32 ? launch_gemv<WQ, EPI_F32>(s, x, w, scale, group, M, N, K, y, ldy)               \

@@ -241,7 +241,11 @@ __global__ __launch_bounds__(NW * 64) void gemv_stream_kernel(const uint16_t* __
 
 // largest M this kernel takes; 0 when the shape does not fit it (the caller then uses the tile kernels)
 int gemv_stream_max_m(int wq_bit, int group, int N, int K) {
-    static const int max_m = getenv("PPLHIP_GEMV_STREAM_MAX_M") ? atoi(getenv("PPLHIP_GEMV_STREAM_MAX_M")) : 4;
+    // default: 4 rows; 2 for int8 weights that the half-height tile kernel of k_gemm.hip takes (K % 128 == 0) -- with 16-row activation
+    // sub-tiles and one block per CU it overtakes the GEMV from 3 rows (7B decode step at batch 2 / 3 / 4 / 5: GEMV 2.48 / 2.75 / 3.00 / -,
+    // tiles - / see DESIGN.md / 2.68 / 2.74 ms)
+    static const int env_m = getenv("PPLHIP_GEMV_STREAM_MAX_M") ? atoi(getenv("PPLHIP_GEMV_STREAM_MAX_M")) : -1;
+    const int max_m = env_m >= 0 ? env_m : (wq_bit == 8 && K % 128 == 0 ? 2 : 4);
     const int kl = wq_bit == 8 ? 16 : (wq_bit == 4 ? 32 : 8);
     if (K % kl) return 0;
     if (wq_bit == 4 && (group % 32 || K % group)) return 0;

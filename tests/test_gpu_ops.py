@@ -571,6 +571,20 @@ def test_linear_streaming_gemv_swiglu(wq, M, inter, K):
     test_linear_swiglu_fused(wq, M, inter, K)
 
 
+def test_linear_streaming_gemv_int8_three_and_four_rows():
+    """int8 weights at 3 and 4 rows go to the half-height tile kernel by default (round 4: it overtook the GEMV there); the GEMV's 3- and 4-row int8
+    instantiation stays reachable with PPLHIP_GEMV_STREAM_MAX_M=4 and is held against the oracle here (child process: the switch is read once)."""
+    import subprocess, sys, os
+    code = ("import tests.test_gpu_ops as t\n"
+            "for N, K in [(4096, 4096), (4096, 11008), (1000, 384), (640, 24576)]:\n"
+            "    t.test_linear(8, 4, N, K)\n"
+            "    t.test_linear(8, 3, N, K)\n"
+            "t.test_linear_swiglu_fused(8, 4, 3000, 11008)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PPLHIP_GEMV_STREAM_MAX_M="4"), cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 @pytest.mark.parametrize("M", [5, 16, 33, 64])
 @pytest.mark.parametrize("N,K", [(4096, 4096), (12288, 4096), (4096, 11008), (1000, 384), (520, 128), (8192, 1024)])
 def test_linear_w8_half_height_tiles_with_128_deep_k_tiles(M, N, K):
