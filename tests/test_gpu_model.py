@@ -427,7 +427,7 @@ def _defer_case_logits(wq, kvq, batch, steps=3):
     return res
 
 
-@pytest.mark.parametrize("wq,kvq,batch", [(8, 8, 6), (8, 8, 40), (0, 0, 24), (8, 0, 200), (4, 8, 12), (8, 8, 130)])
+@pytest.mark.parametrize("wq,kvq,batch", [(8, 8, 6), (8, 8, 40), (0, 0, 24), (8, 0, 200), (4, 8, 12), (8, 8, 130), (8, 8, 100), (8, 0, 3)])
 def test_split_k_slabs_reduced_by_the_consuming_kernel(wq, kvq, batch):
     """tensor-parallel size 1, 4 < M <= 256: the split-K slabs of wqkv / wo / w2 are summed by RoPE + KV write and by the (Skip)RMSNorms
     that consume them instead of a reduce kernel of their own (kernels.h SplitSlabs) -- against the oracle, and BIT-identical to the
