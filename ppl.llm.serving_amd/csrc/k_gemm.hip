@@ -827,9 +827,10 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         // W8, half-height tiles: the 128-deep K tile (whole 128-byte lines of every weight row per LDS-DMA piece; gemm_w8_half128_kernel),
         // activation sub-tile 16 / 32 / 64 rows; three stages when two blocks of them fit a CU (BM <= 32) or the grid is one block per CU
         static const int half128 = getenv("PPLHIP_GEMM_HALF128") ? atoi(getenv("PPLHIP_GEMM_HALF128")) : 1;  // 0: off; 2: always 64-row sub-tiles
-        // ... and 64 < M <= 128 with a 128-row sub-tile (three stages = 144 KiB, one block per CU) for the shapes that need split-K anyway
-        // (7B at M = 128, HBM-cold: wqkv 33.1 -> 29.3 us, wo 21.2 -> 18.9, w2 27.9 -> 26.3; w13 -- 172 tiles, no split -- stays on the
-        // 128 x 128 ring kernel with its eight consumer waves: 34.7 against 42.0 us).  PPLHIP_GEMM_HALF128_MAX_M=64: off
+        // ... and 64 < M <= 128 with 80- .. 128-row sub-tiles (steps of 16 rows; three stages, one block per CU) for the shapes that need split-K
+        // anyway (7B at M = 128, HBM-cold: wqkv 33.1 -> 29.3 us, wo 21.2 -> 18.9, w2 27.9 -> 26.3; w13 -- 172 tiles, no split -- stays on the
+        // 128 x 128 ring kernel with its eight consumer waves above 80 rows: 34.7 against 42.0 us at 128).  Decode step at batch 72 / 96 / 128
+        // 6.20 / 6.85 / 7.92 -> 5.70 / 6.53 / 7.76 ms.  PPLHIP_GEMM_HALF128_MAX_M=64: off
         static const int half128_max_m = getenv("PPLHIP_GEMM_HALF128_MAX_M") ? atoi(getenv("PPLHIP_GEMM_HALF128_MAX_M")) : 128;
         // split-K slabs: ONE block per CU, not three.  A slab costs 8 M N bytes (written here, read by the reduce or the consuming
         // kernel) against N K / splits weight bytes -- at M = 64 and K / splits = 683 that is 0.75 extra bytes per weight byte, and it
@@ -845,18 +846,20 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
             while (sp > 1 && (size_t)sp * M * N * sizeof(float) > ws_bytes) --sp;
         }
         if (sp > kt128) sp = kt128 > 0 ? kt128 : 1;
-        if (half128 && (half || (M <= 128 && M <= half128_max_m && sp > 1 && m_tiles == 1)) && wq_bit == 8 && K % (G_BK * S_KS) == 0) {
+        static const int half128_unsplit_max_m = getenv("PPLHIP_GEMM_HALF128_UNSPLIT_MAX_M") ? atoi(getenv("PPLHIP_GEMM_HALF128_UNSPLIT_MAX_M")) : 80;  // (w13: 80-row sub-tile 31.0-31.6 vs 32.4-32.6 us at M = 72-80, 96 rows 34.4 vs 33.1)
+        if (half128 && (half || (M <= 128 && M <= half128_max_m && (sp > 1 || M <= half128_unsplit_max_m) && m_tiles == 1)) && wq_bit == 8 && K % (G_BK * S_KS) == 0) {
             const int kt_per128 = (kt128 + sp - 1) / sp;
             sp = (kt128 + kt_per128 - 1) / kt_per128;
-            const int bm = M > 64 ? 128 : (half128 == 2 ? 64 : (M <= 16 ? 16 : (M <= 32 ? 32 : 64)));
-            const int st = (bm <= 32 || bm == 128 || (int64_t)n_tiles * sp <= 256) ? 3 : 2;
-            const size_t lds = (size_t)st * ((bm == 16 ? s_xb<16>() : bm == 32 ? s_xb<32>() : bm == 64 ? s_xb<64>() : s_xb<128>()) + S_WB);
+            // (above 64 rows in steps of 16: a 72-row step on a 128-row sub-tile would pay 128 rows of LDS traffic and MFMAs)
+            const int bm = M > 64 ? (int)((M + 15) / 16 * 16) : (half128 == 2 ? 64 : (M <= 16 ? 16 : (M <= 32 ? 32 : 64)));
+            const int st = (bm <= 32 || bm > 64 || (int64_t)n_tiles * sp <= 256) ? 3 : 2;
+            const size_t lds = (size_t)st * ((size_t)S_KS * bm * G_BK * 2 + S_WB);
             static bool attr_dev[64] = {false};
             int dev = 0;
             (void)hipGetDevice(&dev);
             if (!attr_dev[dev & 63]) {
 #define H128_A(E, S, B) (void)hipFuncSetAttribute((const void*)gemm_w8_half128_kernel<E, S, B>, hipFuncAttributeMaxDynamicSharedMemorySize, S * (s_xb<B>() + S_WB))
-#define H128_AE(E) H128_A(E, 3, 16); H128_A(E, 3, 32); H128_A(E, 2, 64); H128_A(E, 3, 64); H128_A(E, 3, 128)
+#define H128_AE(E) H128_A(E, 3, 16); H128_A(E, 3, 32); H128_A(E, 2, 64); H128_A(E, 3, 64); H128_A(E, 3, 80); H128_A(E, 3, 96); H128_A(E, 3, 112); H128_A(E, 3, 128)
                 H128_AE(EPI_F16); H128_AE(EPI_F32); H128_AE(EPI_SWIGLU);
 #undef H128_AE
 #undef H128_A
@@ -864,7 +867,8 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
             }
             dim3 gh((unsigned)n_tiles, (unsigned)sp);
 #define H128_L(E, S, B) hipLaunchKernelGGL((gemm_w8_half128_kernel<E, S, B>), gh, dim3(256), lds, s, x, (const int8_t*)w, scale, M, N, K, y, ldy, n_tiles, kt_per128, ws)
-#define H128_E(E) do { if (bm == 16) H128_L(E, 3, 16); else if (bm == 32) H128_L(E, 3, 32); else if (bm == 128) H128_L(E, 3, 128); else if (st == 3) H128_L(E, 3, 64); else H128_L(E, 2, 64); } while (0)
+#define H128_E(E) do { if (bm == 16) H128_L(E, 3, 16); else if (bm == 32) H128_L(E, 3, 32); else if (bm == 80) H128_L(E, 3, 80); else if (bm == 96) H128_L(E, 3, 96); \
+                         else if (bm == 112) H128_L(E, 3, 112); else if (bm == 128) H128_L(E, 3, 128); else if (st == 3) H128_L(E, 3, 64); else H128_L(E, 2, 64); } while (0)
             if (epi == EPI_F32) H128_E(EPI_F32); else if (epi == EPI_F16) H128_E(EPI_F16); else H128_E(EPI_SWIGLU);
 #undef H128_E
 #undef H128_L

@@ -585,11 +585,11 @@ def test_linear_streaming_gemv_int8_three_and_four_rows():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
 
 
-@pytest.mark.parametrize("M", [5, 16, 33, 64, 65, 100, 128])
+@pytest.mark.parametrize("M", [5, 16, 20, 33, 64, 65, 96, 100, 128])
 @pytest.mark.parametrize("N,K", [(4096, 4096), (12288, 4096), (4096, 11008), (1000, 384), (520, 128), (8192, 1024)])
 def test_linear_w8_half_height_tiles_with_128_deep_k_tiles(M, N, K):
     """2 < M <= 64, W8A16, K % 128 == 0: gemm_w8_half128_kernel (whole 128-byte lines of every weight row per LDS-DMA piece; split-K slabs
-    at the 7B layer shapes, a single split at the small ones); 64 < M <= 128: its 128-row form for the shapes that take split-K slabs."""
+    at the 7B layer shapes, a single split at the small ones); 64 < M <= 128: the same kernel with 80- .. 128-row sub-tiles for the shapes that take split-K slabs."""
     test_linear(8, M, N, K)
 
 
