@@ -1445,7 +1445,9 @@ static int run_launches(pplhip_ctx* c, int rank) {
 // shape captures it).  Measured (profiles/small_batch_latency.py, 7B W8A16, kv 512): batch 1 3.30 ms replayed vs 3.26 ms eager,
 // batch 64 6.08 vs 6.07 -- the step is GPU-bound (the kernels already run back to back; what a small batch loses is the ramp-up
 // of 290 short kernels, which a graph does not remove), so the replay only saves host time and stays opt-in
-// (PPLHIP_DECODE_GRAPH=1).  Never under tensor parallelism (collectives on a second stream) or profiling.
+// (PPLHIP_DECODE_GRAPH=1).  Round 4, with the step at 2.3 ms: batch 1 / 2 2.33 / 2.53 -> 2.28 / 2.48 ms replayed, nothing from batch 4 up;
+// still opt-in (a paged cache changes the page-table width, hence the captured shape, every page_size steps).
+// Never under tensor parallelism (collectives on a second stream) or profiling.
 static int run_decode_graph(pplhip_ctx* c, int rank, bool* done) {
     Rank& R = c->ranks[rank];
     *done = false;
