@@ -247,7 +247,7 @@ class KvCase:
 
 @pytest.mark.parametrize("quant", [0, 8])
 @pytest.mark.parametrize("layout,mode", [(0, 0), (1, 1), (2, 0), (3, 1), (3, 0)])
-@pytest.mark.parametrize("H,Hkv,D", [(4, 4, 32), (8, 2, 64), (4, 4, 128)])
+@pytest.mark.parametrize("H,Hkv,D", [(4, 4, 32), (8, 2, 64), (4, 4, 128), (32, 8, 128), (32, 32, 128)])   # the last two: 2 / 4 blocks per token
 def test_rope_kv_write(quant, layout, mode, H, Hkv, D):
     m = load_pplhip()
     case = KvCase(m, H, Hkv, D, L=3, layer=1, quant=quant, layout=layout, mode=mode, seqlens=[5, 1, 9, 1],
@@ -569,6 +569,18 @@ def test_linear_streaming_gemv(wq, M, N, K):
 @pytest.mark.parametrize("M,inter,K", [(1, 11008, 4096), (2, 1376, 512), (3, 100, 128), (1, 40, 4096), (4, 3000, 11008)])
 def test_linear_streaming_gemv_swiglu(wq, M, inter, K):
     test_linear_swiglu_fused(wq, M, inter, K)
+
+
+def test_rope_kv_write_three_blocks_per_token():
+    """a block count that does not divide a token's work items (PPLHIP_ROPE_BLOCKS_PER_TOKEN=3; child process: the switch is read once)"""
+    import subprocess, sys, os
+    code = ("import tests.test_gpu_ops as t\n"
+            "for q in (0, 8):\n"
+            "    t.test_rope_kv_write(q, 3, 1, 32, 8, 128)\n"
+            "    t.test_rope_kv_write(q, 3, 0, 4, 4, 32)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PPLHIP_ROPE_BLOCKS_PER_TOKEN="3"), cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_linear_streaming_gemv_int8_three_and_four_rows():
