@@ -6,8 +6,9 @@
 //   * precision: the round-2 kernel rounded the dequantised K / V (int8 x fp16 scale: 19 significant bits) and the
 //     probabilities to fp16 for the MFMAs and landed 4e-3 from the oracle at kv 2048 (70B / TP8 geometry), six times the
 //     oracle's own summation-order noise.  Now every MFMA operand is an exact hi + lo pair of fp16 numbers:
-//       K, V : hi = fp16(q * s) (packed multiply), lo = fma(q, s, -hi) -- the error term of a floating-point product is itself
-//              exactly representable (TwoProduct), so hi + lo == q * s exactly, for 1.5 packed VALU ops per element;
+//       K (V) : hi = fp16(q * s) (packed multiply), lo = fma(q, s, -hi) -- the error term of a floating-point product is itself
+//              exactly representable (TwoProduct), so hi + lo == q * s exactly, for 1.5 packed VALU ops per element
+//              (V: only with GQ_V_EXACT = 1, see below; by default V is the hi term alone);
 //       P    : hi = fp16(p), lo = fp16(p - hi) (22 significant bits);
 //     S = Q.(Khi + Klo)  (two MFMAs per k-step), O += (Phi + Plo).(Vhi + Vlo).  The P.V MFMA contracts over 32 k-slots but
 //     a wave's sub-tile has only 16 keys, so the lo terms ride in the k-slots that used to be zero: A = (Phi | Plo),
@@ -35,6 +36,13 @@ constexpr int GQ_THREADS = GQ_THREADS_N;
 constexpr int GQ_WAVES = GQ_THREADS / 64;
 #ifndef GQ_NBUF
 #define GQ_NBUF 2   // measured 2 / 3 / 4: 4.46 / 4.07 / 4.16 TB/s at B 256, kv 2048 (the kernel is issue-bound, not latency-bound): 16-key sub-tiles in flight per wave (register buffers, statically rotated)
+#endif
+// GQ_V_EXACT 0 (round 4, default): V = int8 x scale rounded to fp16 ONCE (round to nearest, as both prefill kernels take it) -- one LDS image,
+// one MFMA per channel block, 16 packed VALU ops less per sub-tile: config 4 (B 256, kv 2048, 8 : 1) 4.48-4.62 -> 4.84 TB/s = 60.5 % of 8 TB/s;
+// against the oracle 6.4e-5 -> 2.6e-4 of max|out| at that shape (tolerance 1.5e-3; K, whose rounding the exponent amplifies -- the round-2
+// kernel's 4e-3 -- and P stay exact hi + lo pairs).  1: V as an exact hi + lo pair as well (round 3).
+#ifndef GQ_V_EXACT
+#define GQ_V_EXACT 0
 #endif
 constexpr int GQ_VSUB = 272;  // halfs per [16 keys][16 channels] V sub-tile in LDS: 256 + 16 of skew (bank spread of the writes)
 
@@ -69,7 +77,7 @@ __global__ __launch_bounds__(GQ_THREADS) void attn_decode_gqa_kernel(const uint1
     constexpr int PPL = LPT / 4;        // pieces per lane and 16-key sub-tile (K and V alike)
     constexpr int KSTEPS = D / 32;
     constexpr int DT = D / 16;
-    constexpr int NIMG = QBIT == 8 ? 2 : 1;           // V images in LDS: hi (+ lo)
+    constexpr int NIMG = (QBIT == 8 && GQ_V_EXACT) ? 2 : 1;           // V images in LDS: hi (+ lo)
     constexpr int VW = DT * GQ_VSUB;                  // halfs of one image of one wave's 16-key sub-tile
     static_assert(LPT % 4 == 0, "a row must hold a multiple of four 16-byte pieces");
     constexpr int V_BYTES = GQ_WAVES * NIMG * VW * 2, MERGE_BYTES = GQ_WAVES * 16 * (D + 2) * 4;
@@ -192,14 +200,19 @@ __global__ __launch_bounds__(GQ_THREADS) void attn_decode_gqa_kernel(const uint1
             if constexpr (QBIT == 8) {
                 const h8 q0 = cvt_i8x8_f16(make_uint2(vraw[P][j].x, vraw[P][j].y)), q1 = cvt_i8x8_f16(make_uint2(vraw[P][j].z, vraw[P][j].w));
                 const h2 sc = __builtin_bit_cast(h2, vsc[P][j]);
-                h8 hi0, lo0, hi1, lo1;
-                two_product(q0, sc[0], hi0, lo0);
-                two_product(q1, sc[1], hi1, lo1);
                 uint16_t* dst = vw + (ch0 >> 4) * GQ_VSUB + key * 16;  // CH = 16: the piece is one whole sub-tile row
-                *reinterpret_cast<uint4*>(dst) = __builtin_bit_cast(uint4, hi0);
-                *reinterpret_cast<uint4*>(dst + 8) = __builtin_bit_cast(uint4, hi1);
-                *reinterpret_cast<uint4*>(dst + VW) = __builtin_bit_cast(uint4, lo0);
-                *reinterpret_cast<uint4*>(dst + VW + 8) = __builtin_bit_cast(uint4, lo1);
+                if constexpr (GQ_V_EXACT) {
+                    h8 hi0, lo0, hi1, lo1;
+                    two_product(q0, sc[0], hi0, lo0);
+                    two_product(q1, sc[1], hi1, lo1);
+                    *reinterpret_cast<uint4*>(dst) = __builtin_bit_cast(uint4, hi0);
+                    *reinterpret_cast<uint4*>(dst + 8) = __builtin_bit_cast(uint4, hi1);
+                    *reinterpret_cast<uint4*>(dst + VW) = __builtin_bit_cast(uint4, lo0);
+                    *reinterpret_cast<uint4*>(dst + VW + 8) = __builtin_bit_cast(uint4, lo1);
+                } else {
+                    *reinterpret_cast<uint4*>(dst) = __builtin_bit_cast(uint4, q0 * splat8(sc[0]));
+                    *reinterpret_cast<uint4*>(dst + 8) = __builtin_bit_cast(uint4, q1 * splat8(sc[1]));
+                }
             } else {
                 *reinterpret_cast<uint4*>(vw + (ch0 >> 4) * GQ_VSUB + key * 16 + (ch0 & 15)) = vraw[P][j];
             }
@@ -267,7 +280,7 @@ __global__ __launch_bounds__(GQ_THREADS) void attn_decode_gqa_kernel(const uint1
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const uint2 vh = gq_v_frag(vw + dt * GQ_VSUB, kq, l15);  // keys kq*4 .. +4 of channel dt*16 + l15
-            if constexpr (QBIT == 8) {
+            if constexpr (QBIT == 8 && GQ_V_EXACT) {
                 const uint2 vl = gq_v_frag(vw + VW + dt * GQ_VSUB, kq, l15);
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, __builtin_bit_cast(h8, make_uint4(vl.x, vl.y, vl.x, vl.y)), o[dt], 0, 0, 0);
             }

@@ -22,6 +22,9 @@ namespace pplhip {
 namespace {
 
 constexpr int P3_BN = 64, P3_D = 128;
+#ifndef P3_P_EXACT
+#define P3_P_EXACT 1
+#endif
 constexpr int P3_VSUB = 272;  // halfs per [16 keys][16 channels] V sub-tile: 256 + 16 of skew
 constexpr int P3_KS_HALFS = P3_BN * P3_D, P3_VS_HALFS = (P3_BN / 16) * (P3_D / 16) * P3_VSUB;
 typedef float f16v __attribute__((ext_vector_type(16)));
@@ -282,26 +285,33 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     for (int c = 0; c < 4; ++c) o[c][i] *= ar;
                 }
             }
-            // ---- O += P . V over four 16-key k-steps; P as an exact hi + lo pair (mask, subtract, v_cvt_pkrtz) ---------------------
+            // ---- O += P . V over four 16-key k-steps.  P3_P_EXACT 1: P as an exact hi + lo pair (mask, subtract, v_cvt_pkrtz: two MFMAs per
+            // block); 0: P rounded to NEAREST fp16 once (unbiased, relative error <= 2^-12; one MFMA) --------------------------------------
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 typedef __fp16 pk_h2 __attribute__((ext_vector_type(2)));
-                uint32_t hw[4], lw[4];
+                h8 pa, pl;
+                if constexpr (P3_P_EXACT) {
+                    uint32_t hw[4], lw[4];
 #pragma unroll
-                for (int q2 = 0; q2 < 4; ++q2) {
-                    const float p0 = sacc[s >> 1][8 * (s & 1) + 2 * q2], p1 = sacc[s >> 1][8 * (s & 1) + 2 * q2 + 1];
-                    const float h0 = __uint_as_float(__float_as_uint(p0) & 0xffffe000u), h1 = __uint_as_float(__float_as_uint(p1) & 0xffffe000u);
-                    hw[q2] = __builtin_bit_cast(uint32_t, (pk_h2)__builtin_amdgcn_cvt_pkrtz(h0, h1));
-                    lw[q2] = __builtin_bit_cast(uint32_t, (pk_h2)__builtin_amdgcn_cvt_pkrtz(p0 - h0, p1 - h1));
+                    for (int q2 = 0; q2 < 4; ++q2) {
+                        const float p0 = sacc[s >> 1][8 * (s & 1) + 2 * q2], p1 = sacc[s >> 1][8 * (s & 1) + 2 * q2 + 1];
+                        const float h0 = __uint_as_float(__float_as_uint(p0) & 0xffffe000u), h1 = __uint_as_float(__float_as_uint(p1) & 0xffffe000u);
+                        hw[q2] = __builtin_bit_cast(uint32_t, (pk_h2)__builtin_amdgcn_cvt_pkrtz(h0, h1));
+                        lw[q2] = __builtin_bit_cast(uint32_t, (pk_h2)__builtin_amdgcn_cvt_pkrtz(p0 - h0, p1 - h1));
+                    }
+                    pa = __builtin_bit_cast(h8, make_uint4(hw[0], hw[1], hw[2], hw[3]));
+                    pl = __builtin_bit_cast(h8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) pa[q] = (_Float16)sacc[s >> 1][8 * (s & 1) + q];
                 }
-                const h8 pa = __builtin_bit_cast(h8, make_uint4(hw[0], hw[1], hw[2], hw[3]));
-                const h8 pl = __builtin_bit_cast(h8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const uint16_t* sub = Vs + (s * (D / 16) + 2 * c + chblk) * P3_VSUB;  // keys 16 s .. + 16, channels 32 c + 16 chblk .. + 16
                     const uint2 v0 = p3_v_frag(sub, 4 * hi, l15), v1 = p3_v_frag(sub, 8 + 4 * hi, l15);
                     const h8 bv = __builtin_bit_cast(h8, make_uint4(v0.x, v0.y, v1.x, v1.y));
-                    if (!(ABL & 1)) o[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, bv, o[c], 0, 0, 0);
+                    if constexpr (P3_P_EXACT) { if (!(ABL & 1)) o[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, bv, o[c], 0, 0, 0); }
                     o[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa, bv, o[c], 0, 0, 0);
                 }
             }
