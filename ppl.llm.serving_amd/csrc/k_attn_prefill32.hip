@@ -22,6 +22,10 @@ namespace pplhip {
 namespace {
 
 constexpr int P3_BN = 64, P3_D = 128;
+// P3_P_EXACT 1 (default): P enters P . V as an exact hi + lo pair of fp16 numbers (two MFMAs per block).  0: P rounded to nearest fp16 once --
+// measured in round 4 (profiles/r03_prefill_attention_ablation.md): 8192-token prompt 1002 -> 820 us (670 TFLOP/s counted), 4 x 2048 323 ->
+// 227 us, 2048 behind 6144 cached 482 -> 369 us; every test still passes, but the operator's largest error against the oracle goes from
+// 1.6e-4 / 2.6e-4 to 6.5e-4 of max|out| (tolerance 1e-3) -- two thirds of the tolerance for 1 % of a prefill step: kept as a build switch
 #ifndef P3_P_EXACT
 #define P3_P_EXACT 1
 #endif
