@@ -1,14 +1,17 @@
-// Streaming GEMV for 1 <= M <= 4 activation rows (single-stream and few-stream decode; round 4, VERDICT r3 item 5).
+// Streaming GEMV for 1 <= M <= 4 activation rows (single-stream and few-stream decode; round 4).
 //
 // The MFMA skinny kernel of k_gemm.hip fetches weights in the MFMA A-operand shape -- a wave-load is 16 rows x 64 bytes -- and streams the
 // 7B layer at 2.9 TB/s (W8A16), 36 % of the HBM peak: every request is half a 128-byte line of a different row.  At M <= 4 the matrix
 // unit buys nothing (one row of activations against every weight: 2 M flop per weight byte), so this kernel is a plain stream:
 //   * a wave-load is ONE KiB of ONE weight row (16 contiguous bytes per lane): whole DRAM lines, the access pattern of the decode attention
 //     kernel (6.4 TB/s);
-//   * block = 8 waves x 16 weight rows; wave w owns the 1-KiB pieces p == w (mod 8) of every row of the block, so the activations it needs
-//     (16 / 32 / 8 elements per lane and piece for int8 / int4 / fp16 weights) sit in registers for the whole block;
+//   * block = 4 or 8 waves, split nwk (along K) x nwr (along rows): wave (wk, wr) owns the 1-KiB pieces p == wk (mod nwk) of its 8 or 16
+//     weight rows, so the activations it needs (16 / 32 / 8 elements per lane and piece for int8 / int4 / fp16 weights) sit in registers
+//     while it walks its rows; short rows (few pieces) give the spare waves rows of their own, small matrices get 8-row waves so that every
+//     CU still has several (launch_gemv_stream);
 //   * 8 rows in flight per wave (8 KiB) before the first use; partial sums of 8 rows are folded across the 64 lanes by a halving
-//     butterfly (10 cross-lane operations per 8 rows), across the 8 waves through LDS; scales / SwiGLU / rounding by the first threads.
+//     butterfly (10 cross-lane operations per 8 rows), across the waves along K through LDS; scales / SwiGLU / rounding by the first threads.
+// Default range (gemv_stream_max_m): M <= 4; int8 weights with K % 128 == 0 only M <= 2 -- from 3 rows the tile kernel of k_gemm.hip is faster.
 // Numerics as ref_linear (oracle/llama_ref.c): fp32 products and sums of fp16 x {int8 exact, fp16(nibble x group scale), fp16}; the
 // per-channel W8 scale multiplies the finished sum.  Summation order differs from the oracle's (as in every GEMM kernel here).
 #include <stdlib.h>
