@@ -89,6 +89,7 @@ struct Rank {
     // w2 -> the next layer's attention norm (or the final norm)
     SplitSlabs sl_qkv, sl_part, sl_part2;
     bool defer_reduce = false;   // this step: tensor-parallel size 1, weight-only quantisation, no residual dump
+    bool defer_qkv = false;      // ... wqkv's slabs alone also under tensor parallelism (RoPE + KV write consumes them on the rank itself)
 
     // activations
     uint16_t *h = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *part = nullptr, *part2 = nullptr, *gu = nullptr,
@@ -1141,7 +1142,7 @@ static int layer_linear(pplhip_ctx* c, int rank, const Linear& l, const uint16_t
         return 0;
     }
     HIPCK(c, rank, launch_linear(R.stream, x, l.w, l.scale, l.qbit, l.group, M, l.N, l.Kp, y, ldy, false, R.gemm_ws, R.gemm_ws_bytes, swiglu,
-                                 R.defer_reduce ? defer : nullptr));
+                                 (R.defer_reduce || (R.defer_qkv && defer == &R.sl_qkv)) ? defer : nullptr));
     return 0;
 }
 
@@ -1364,6 +1365,7 @@ static int run_launches(pplhip_ctx* c, int rank) {
 
     static const int defer_on = getenv("PPLHIP_DEFER_REDUCE") ? atoi(getenv("PPLHIP_DEFER_REDUCE")) : 1;
     R.defer_reduce = defer_on && !comm && d.act_quant_bit != 8 && !R.dump_dev && nck == 1;
+    R.defer_qkv = defer_on && d.act_quant_bit != 8 && !R.dump_dev && nck == 1;   // (wo / w2 feed the all-reduce: their slabs are summed first)
     R.sl_qkv = R.sl_part = R.sl_part2 = SplitSlabs{};
     ProfEvent ev_run, ev;
     prof_begin(c, R, PPLHIP_PROF_RUN, &ev_run);
