@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(uint16_t* __restrict
             uint16_t* x = row + (int64_t)head * D;
             float a[8], bb[8], c[8], s[8], ra[8], rb[8];
             if (sl.splits) {  // the qkv rows straight from wqkv's unreduced split-K slabs (kernels.h SplitSlabs)
-                slab_load8(sl, t, head * D + i0, a);
-                slab_load8(sl, t, head * D + i0 + half, bb);
+                slab_load8(sl, t - t0, head * D + i0, a);   // (slab rows count from the launch's first row)
+                slab_load8(sl, t - t0, head * D + i0 + half, bb);
             } else {
                 unpack8(*reinterpret_cast<const uint4*>(x + i0), a);
                 unpack8(*reinterpret_cast<const uint4*>(x + i0 + half), bb);
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(uint16_t* __restrict
             const int wv = w - n_rope;
             const int head = wv / (D / 8), i0 = (wv - head * (D / 8)) * 8;
             float v[8];
-            if (sl.splits) slab_load8(sl, t, (H + Hkv + head) * D + i0, v);
+            if (sl.splits) slab_load8(sl, t - t0, (H + Hkv + head) * D + i0, v);
             else unpack8(*reinterpret_cast<const uint4*>(row + (int64_t)(H + Hkv + head) * D + i0), v);
             store_group8<QBIT>(kv, 1, head, slot, i0, v);
         }
@@ -121,7 +121,7 @@ hipError_t launch_rope_kv_write(hipStream_t s, uint16_t* qkv, const float* cos_s
     SplitSlabs sl;
     if (qkv_slabs && qkv_slabs->splits > 0) {
         sl = *qkv_slabs;
-        if (t0 != 0 || sl.N != (H + 2 * Hkv) * D) return hipErrorInvalidValue;
+        if (sl.N != (H + 2 * Hkv) * D || sl.M != T) return hipErrorInvalidValue;
     }
     if (D % 16 || (quant_bit == 8 && quant_group != 8) || (quant_bit != 0 && quant_bit != 8)) return hipErrorInvalidValue;
     const int items = (H + Hkv) * (D / 16) + Hkv * (D / 8);

@@ -66,7 +66,7 @@ hipError_t launch_rope_kv_write(hipStream_t s, uint16_t* qkv, const float* cos_s
                                 int quant_group, const int64_t* seq_starts, const int64_t* start_pos,
                                 const int64_t* cache_indices, int64_t max_pages, int64_t B, int64_t t0, int64_t T, int H,
                                 int Hkv, int D, const SplitSlabs* qkv_slabs = nullptr);  // token rows [t0, t0 + T) of the step's B requests;
-                                                   // qkv_slabs: the rows come from unreduced split-K slabs (t0 must be 0); rotated q -> qkv
+                                                   // qkv_slabs: the rows come from unreduced split-K slabs of a [T, N] launch (slab row = token row - t0); rotated q -> qkv
 
 // ---- k_attn_decode.hip ------------------------------------------------------------------------
 // rows [0, nb) of the batch are single-token queries; q row of request b is qkv row seq_starts[b].

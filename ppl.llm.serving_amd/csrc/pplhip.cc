@@ -56,6 +56,13 @@ struct Rank {
     hipStream_t stream = nullptr;
     ncclComm_t comm = nullptr;
     hipStream_t comm_stream = nullptr;  // collectives of an overlapped step (pplhip_run)
+    // two-stream decode (run_launches, "dual"): the second half of a mid-size pure-decode step runs its layers on stream2, beside the first
+    // half on `stream`, with split-K / attention workspaces of its own; ev_fork / ev_join order the two around the step
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    float* gemm_ws2 = nullptr;
+    bool dual_seen = false;
+    bool keep_part2 = false;            // this launch of w2 must write part2 (its consumer runs on the other stream): no deferred slabs
     hipEvent_t ev_compute[2] = {nullptr, nullptr}, ev_comm[2] = {nullptr, nullptr};
     const int64_t* h_seq = nullptr;     // host copy of this step's seq_starts (lives in the staging buffer)
     std::string err;
@@ -158,6 +165,9 @@ struct pplhip_ctx {
     int comm_want = 0;      // 0 auto, 1 rccl only, 2 p2p only
     bool p2p_connected = false;
     uint64_t p2p_timeout_ticks = 0;  // s_memrealtime ticks (100 MHz)
+    // PPLHIP_DUAL_STREAM=1: pure-decode steps of dual_min_rows..dual_max_rows rows as two half-batches on two streams (run_launches)
+    int dual_mode = 0;
+    int64_t dual_min_rows = 96, dual_max_rows = 512;
     bool graph_on = false;           // PPLHIP_DECODE_GRAPH=1: replay pure-decode steps as HIP graphs (opt-in, see run_decode_graph)
     int64_t graph_max_batch = 64;    // above this a step is seconds of GPU work per thousand launches: nothing to gain
     int H = 0, Hkv = 0, D = 0, inter = 0, vocab_local = 0;
@@ -491,6 +501,9 @@ void pplhip_destroy(pplhip_ctx* c) {
         hipSetDevice(R.device);
         if (R.stream) hipStreamSynchronize(R.stream);
         if (R.comm_stream) hipStreamSynchronize(R.comm_stream);
+        if (R.stream2) { hipStreamSynchronize(R.stream2); hipStreamDestroy(R.stream2); }
+        if (R.ev_fork) hipEventDestroy(R.ev_fork);
+        if (R.ev_join) hipEventDestroy(R.ev_join);
         if (R.comm) ncclCommDestroy(R.comm);
         if (R.comm_stream) hipStreamDestroy(R.comm_stream);
         for (int i = 0; i < 2; ++i) {
@@ -580,6 +593,9 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
     const bool want_comm = tp > 1 || getenv("PPLHIP_FORCE_COMM") != nullptr;
     c->tp_on = want_comm;
     if (const char* e = getenv("PPLHIP_DECODE_GRAPH")) c->graph_on = atoi(e) != 0;
+    if (const char* e = getenv("PPLHIP_DUAL_STREAM")) c->dual_mode = atoi(e);
+    if (const char* e = getenv("PPLHIP_DUAL_MIN_ROWS")) c->dual_min_rows = std::max(2, atoi(e));
+    if (const char* e = getenv("PPLHIP_DUAL_MAX_ROWS")) c->dual_max_rows = atoi(e);
     if (const char* e = getenv("PPLHIP_DECODE_GRAPH_MAX_BATCH")) c->graph_max_batch = std::max(1, atoi(e));
     if (const char* e = getenv("PPLHIP_COMM")) c->comm_want = !strcmp(e, "rccl") ? 1 : (!strcmp(e, "p2p") ? 2 : 0);
     {   // bounded spins of the direct collectives: s_memrealtime runs at 100 MHz
@@ -634,6 +650,11 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
         R.global_rank = opts->rank_base + r;
         HIPCK(cp, r, hipSetDevice(R.device));
         HIPCK(cp, r, hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
+        if (c->dual_mode) {
+            HIPCK(cp, r, hipStreamCreateWithFlags(&R.stream2, hipStreamNonBlocking));
+            HIPCK(cp, r, hipEventCreateWithFlags(&R.ev_fork, hipEventDisableTiming));
+            HIPCK(cp, r, hipEventCreateWithFlags(&R.ev_join, hipEventDisableTiming));
+        }
         if (c->tp_on) {
             HIPCK(cp, r, hipStreamCreateWithFlags(&R.comm_stream, hipStreamNonBlocking));
             for (int i = 0; i < 2; ++i) {
@@ -719,6 +740,7 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
         R.gemm_ws_bytes = (size_t)8 * 256 * (size_t)std::max(std::max(2 * c->inter, (c->H + 2 * c->Hkv) * c->D), std::max(hd, c->vocab_local)) * sizeof(float);
         R.gemm_ws_bytes = std::max<size_t>(R.gemm_ws_bytes, (size_t)96 << 20);
         ALLOC(R.gemm_ws, R.gemm_ws_bytes);
+        if (c->dual_mode) ALLOC(R.gemm_ws2, R.gemm_ws_bytes);
 
         if (r == 0) {  // sampler lives on local rank 0 (src/backends/cuda/resource_manager.cc:315-327)
             ALLOC(R.d_temp, cap_B * 4); ALLOC(R.d_topp, cap_B * 4); ALLOC(R.d_rand, cap_B * 4);
@@ -1271,7 +1293,7 @@ static int layer_ffn_part(pplhip_ctx* c, int rank, int l, const Chunk& k) {
     { int rc = layer_linear(c, rank, L.w13, xn, k.tn, act, L.w2.Kp, /*swiglu=*/true, a8); if (rc) return rc; }
     prof_end(R, &ev);
     prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-    { int rc = layer_linear(c, rank, L.w2, act, k.tn, R.part2 + k.t0 * hd, hd, false, false, &R.sl_part2); if (rc) return rc; }
+    { int rc = layer_linear(c, rank, L.w2, act, k.tn, R.part2 + k.t0 * hd, hd, false, false, R.keep_part2 ? nullptr : &R.sl_part2); if (rc) return rc; }
     prof_end(R, &ev);
     return 0;
 }
@@ -1359,13 +1381,57 @@ static int run_launches(pplhip_ctx* c, int rank) {
         nck = 2;
     }
     const bool ov = nck == 2;
+    // Two-stream decode (PPLHIP_DUAL_STREAM=1): a pure-decode step of dual_min_rows..dual_max_rows rows is cut into two half-batches that run
+    // their layers on two streams, side by side.  At these sizes no kernel of the step fills the chip -- the linears are 20-256 tiles with
+    // short K loops, the attention launch a few hundred blocks -- so the halves' kernels interleave on the CUs instead of queueing behind each
+    // other's ramps and tails, and one half's HBM-bound attention runs beside the other's matrix work.  The halves share nothing but the
+    // weights and the KV slab: rows [t0, t0 + tn) of every activation buffer, a split-K workspace and an attention workspace each.  Results
+    // are those of the same rows run as a step of their own.  Not with collectives on a communicator (one stream per communicator),
+    // int8 activations (shared operand buffer), residual dumps or graph capture.
+    const bool identity_comm = comm && c->comm_mode != 2 && !R.comm;   // ranks emulated on one device (bench.py --emulate-tp)
+    bool dual = false;
+    if (c->dual_mode && R.stream2 && !ov && nb_decode == B && T == B && B >= c->dual_min_rows && B <= c->dual_max_rows && B >= 2 &&
+        (!comm || identity_comm) && d.act_quant_bit != 8 && !R.dump_dev) {
+        hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(R.stream, &cst);
+        if (cst == hipStreamCaptureStatusNone) {
+            const int64_t bm = std::min<int64_t>(B - 1, (B / 2 + 15) / 16 * 16);   // whole 16-row activation sub-tiles in the first half
+            ck[0] = Chunk{0, bm, 0, bm, bm};
+            ck[1] = Chunk{bm, B - bm, bm, B - bm, B - bm};
+            nck = 2;
+            dual = true;
+            static const bool verbose = getenv("PPLHIP_VERBOSE") != nullptr;
+            if (verbose && !R.dual_seen) {
+                R.dual_seen = true;
+                fprintf(stderr, "[pplhip] rank %d: two-stream decode (rows %lld + %lld)\n", rank, (long long)bm, (long long)(B - bm));
+            }
+        }
+    }
+    // the second half's launches go out with its own stream, workspaces and deferred-slab state in the rank's working fields
+    struct HalfState { SplitSlabs sl_qkv, sl_part, sl_part2; } half2;
+    const int64_t aws_off = dual ? ck[1].b0 * (int64_t)c->H * 32 * (c->D + 2) : 0;   // floats: past every row the first half can use
+    auto enter2 = [&]() {
+        std::swap(R.stream, R.stream2); std::swap(R.gemm_ws, R.gemm_ws2);
+        R.attn_ws += aws_off; R.attn_ws_bytes -= (size_t)aws_off * 4;
+        std::swap(R.sl_qkv, half2.sl_qkv); std::swap(R.sl_part, half2.sl_part); std::swap(R.sl_part2, half2.sl_part2);
+    };
+    auto leave2 = [&]() {
+        std::swap(R.stream, R.stream2); std::swap(R.gemm_ws, R.gemm_ws2);
+        R.attn_ws -= aws_off; R.attn_ws_bytes += (size_t)aws_off * 4;
+        std::swap(R.sl_qkv, half2.sl_qkv); std::swap(R.sl_part, half2.sl_part); std::swap(R.sl_part2, half2.sl_part2);
+    };
+    struct Half2Guard {   // (an error return between enter2 and leave2 must not leave the rank on the second stream)
+        decltype(leave2)& l; bool in = false;
+        ~Half2Guard() { if (in) l(); }
+    } g2{leave2};
     static const bool tpdbg2 = getenv("PPLHIP_TP_DEBUG") && (atoi(getenv("PPLHIP_TP_DEBUG")) & 2);  // diagnosis: chunks, but collectives in stream
     int split[2] = {1, 1};
     for (int i = 0; i < nck; ++i) split[i] = ck[i].nd > 0 ? decode_split(c, ck[i].nd, R.max_kv_len) : 1;
 
     static const int defer_on = getenv("PPLHIP_DEFER_REDUCE") ? atoi(getenv("PPLHIP_DEFER_REDUCE")) : 1;
-    R.defer_reduce = defer_on && !comm && d.act_quant_bit != 8 && !R.dump_dev && nck == 1;
-    R.defer_qkv = defer_on && d.act_quant_bit != 8 && !R.dump_dev && nck == 1;   // (wo / w2 feed the all-reduce: their slabs are summed first)
+    R.defer_reduce = defer_on && !comm && d.act_quant_bit != 8 && !R.dump_dev && (nck == 1 || dual);
+    R.defer_qkv = defer_on && d.act_quant_bit != 8 && !R.dump_dev && (nck == 1 || dual);   // (wo / w2 feed the all-reduce: their slabs are summed first)
+    R.keep_part2 = false;
     R.sl_qkv = R.sl_part = R.sl_part2 = SplitSlabs{};
     ProfEvent ev_run, ev;
     prof_begin(c, R, PPLHIP_PROF_RUN, &ev_run);
@@ -1374,16 +1440,26 @@ static int run_launches(pplhip_ctx* c, int rank) {
     int rc;
     const size_t dump_n = (size_t)T * hd;  // elements of one dumped matrix
     if (R.dump_dev) HIPCK(c, rank, hipMemcpyAsync(R.dump_dev, R.h, dump_n * 2, hipMemcpyDeviceToDevice, s));
+    if (dual) {   // the second stream starts behind the embedding (and with it behind the step's inputs and the previous step)
+        HIPCK(c, rank, hipEventRecord(R.ev_fork, s));
+        HIPCK(c, rank, hipStreamWaitEvent(R.stream2, R.ev_fork, 0));
+    }
     for (int l = 0; l < d.num_layers; ++l) {
+        // (the last layer's w2 writes part2 in both halves: the final norm gathers rows of both on the first stream)
+        R.keep_part2 = dual && l == d.num_layers - 1;
         for (int i = 0; i < nck; ++i) {
             if (ov && l > 0 && !tpdbg2 && (rc = wait_reduced(c, rank, i))) return rc;  // part2 rows of chunk i are reduced
+            if (dual && i == 1) { enter2(); g2.in = true; }
             if ((rc = layer_attention_part(c, rank, l, ck[i], pending, split[i], threads))) return rc;
             if (comm && (rc = chunk_allreduce(c, rank, R.part, ck[i], i, ov))) return rc;
+            if (g2.in) { leave2(); g2.in = false; }
         }
         for (int i = 0; i < nck; ++i) {
             if (ov && !tpdbg2 && (rc = wait_reduced(c, rank, i))) return rc;            // part rows of chunk i are reduced
+            if (dual && i == 1) { enter2(); g2.in = true; }
             if ((rc = layer_ffn_part(c, rank, l, ck[i]))) return rc;
             if (comm && (rc = chunk_allreduce(c, rank, R.part2, ck[i], i, ov))) return rc;
+            if (g2.in) { leave2(); g2.in = false; }
         }
         pending = R.part2;
         if (R.dump_dev) {
@@ -1393,6 +1469,11 @@ static int run_launches(pplhip_ctx* c, int rank) {
         }
     }
     if (ov && !tpdbg2) for (int i = 0; i < nck; ++i) if ((rc = wait_reduced(c, rank, i))) return rc;
+    R.keep_part2 = false;
+    if (dual) {   // the first stream goes on behind the second half's last layer
+        HIPCK(c, rank, hipEventRecord(R.ev_join, R.stream2));
+        HIPCK(c, rank, hipStreamWaitEvent(s, R.ev_join, 0));
+    }
     // K11: last-token gather + final (Skip)RMSNorm (the last FFN output is folded into the residual of the gathered
     // rows only) + lm_head (+ all-gather of the vocab shards)
     HIPCK(c, rank, launch_rmsnorm(s, R.h, pending, R.norm, d.norm_eps, B, hd, R.d_seq, R.hn, nullptr, nullptr, nullptr, pending ? &R.sl_part2 : nullptr));

@@ -407,9 +407,9 @@ def test_small_batch_decode_with_norms_fused_into_the_streaming_gemv(wq, kvq, ba
     assert (logits.view(np.uint32) == unfused.view(np.uint32)).all(), float(np.abs(logits - unfused).max())
 
 
-def _defer_case_logits(wq, kvq, batch, steps=3):
+def _defer_case_logits(wq, kvq, batch, steps=3, hkv=16):
     m = load_pplhip()
-    desc = ref.make_desc(hidden_dim=2048, intermediate_dim=5632, num_layers=2, num_heads=16, num_kv_heads=16, vocab_size=1024,
+    desc = ref.make_desc(hidden_dim=2048, intermediate_dim=5632, num_layers=2, num_heads=16, num_kv_heads=hkv, vocab_size=1024,
                          max_position=512, cache_quant_bit=kvq, cache_quant_group=8 if kvq else 1, cache_layout=3,
                          cache_mode=0, weight_quant_bit=wq, weight_quant_group=128)
     rm = ref.RefModel(desc)
@@ -448,6 +448,35 @@ def test_split_k_slabs_reduced_by_the_consuming_kernel(wq, kvq, batch):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         plain = np.load(out)
     assert (logits.view(np.uint32) == plain.view(np.uint32)).all(), float(np.abs(logits - plain).max())
+
+
+@pytest.mark.parametrize("wq,kvq,batch,hkv", [(8, 8, 40, 16), (4, 8, 12, 16), (8, 8, 130, 16), (8, 0, 200, 16), (0, 0, 24, 16), (8, 8, 96, 2), (4, 8, 120, 2)])
+def test_two_stream_decode_steps(wq, kvq, batch, hkv):
+    """PPLHIP_DUAL_STREAM=1 (child process: the switch is read at context creation): pure-decode steps run as two half-batches on two
+    streams (pplhip.cc run_launches), each half with its own split-K workspace, attention workspace and deferred-slab state -- the second
+    half's RoPE + KV write and norms read slabs whose rows count from the half's first row.  The child checks its logits against the oracle
+    like every model test; here they are compared with the one-stream step's (the halves' GEMMs pick other tile shapes than the whole
+    batch's, so the two agree within the summation-order noise, not bit for bit)."""
+    import subprocess, sys
+    res = _defer_case_logits(wq, kvq, batch, hkv=hkv)
+    check_steps(res, k=3)
+    logits = np.stack([r[0] for r in res])
+    code = ("import sys, numpy as np\n"
+            "from tests.test_gpu_model import _defer_case_logits, check_steps\n"
+            f"res = _defer_case_logits({wq}, {kvq}, {batch}, hkv={hkv})\n"
+            "check_steps(res, k=3, name='test_two_stream_decode_steps:child')\n"
+            "np.save(sys.argv[1], np.stack([r[0] for r in res]))\n")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "dual.npy")
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, PPLHIP_DUAL_STREAM="1", PPLHIP_DUAL_MIN_ROWS="8", PPLHIP_VERBOSE="1"),
+                           cwd=root, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        assert "two-stream decode" in r.stderr, r.stderr[-2000:]     # the path under test did run
+        dual = np.load(out)
+    assert (logits[0].view(np.uint32) == dual[0].view(np.uint32)).all()    # (the prefill step is not split)
+    scale = max(1.0, float(np.abs(logits).max()))
+    assert float(np.abs(logits - dual).max()) <= 3e-3 * scale
 
 
 def _long_kv_case_logits(kvq, nreq, steps=5):

@@ -92,7 +92,8 @@ def test_rmsnorm(hidden, skip):
                                    (1000, 12000, 192), (1024, 12288, 64),  # W8: the 128 x 384 producer / consumer kernel (ragged edges; one K tile < ring depth)
                                    (4608, 5120, 128), (8192, 2304, 64),   # its super-tile block order: 18 x 20 tiles (3 x 3 super-tiles), 32 x 9 (4 x 2, padded share)
                                    # per-rank shapes of BASELINE configs 3 / 4: 13B/TP2 wqkv and w2, 70B/TP8 wqkv, wo-like and w2
-                                   (300, 7680, 5120), (300, 5120, 6912), (256, 1280, 8192), (64, 8192, 1024), (130, 8192, 3584)])
+                                   (300, 7680, 5120), (300, 5120, 6912), (256, 1280, 8192), (64, 8192, 1024), (130, 8192, 3584),
+                                   (150, 10100, 1792)])   # W4: the 128 x 256 tile kernel with a ragged last tile and two K slabs
 def test_linear(wq, M, N, K):
     m = load_pplhip()
     if wq == 4 and K % 128:
