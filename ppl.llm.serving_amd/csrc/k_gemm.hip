@@ -811,7 +811,15 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         int kt_per = (kt_all + splits - 1) / splits;
         if (wq_bit == 4) kt_per = (kt_per + 1) & ~1;  // whole quantisation groups per split
         splits = (kt_all + kt_per - 1) / kt_per;  // no empty split
-        if (splits > 1) stages = 2;
+        // K slabs: two stages when several blocks share a CU; a launch of at most one block per CU keeps the deep ring (the LDS is free anyway):
+        // W8 7B at M = 256 wo 21.3 -> 19.8 us, w2 38.8 -> 33.4; 13B / TP2 at M = 512 wo 28.0 -> 24.3, w2 56.8 -> 52.1; fp16 70B / TP8 w2 30.0 ->
+        // 26.0; W4 70B / TP8 w2 31.1 -> 30.1 (profiles/r04_splitk_stages_sweep.log).  Until the last session of round 4 this line forced two
+        // stages on EVERY split launch and overrode PPLHIP_GEMM_STAGES, so the earlier stage sweeps never ran 3 / 4 stages on split shapes.
+        static const int split_deep = getenv("PPLHIP_GEMM_SPLIT_DEEP") ? atoi(getenv("PPLHIP_GEMM_SPLIT_DEEP")) : 1;   // 0: always two stages
+        // (W4 half-height tiles at M <= 64 are the exception: w2 of the 70B / TP8 slice 19.4 -> 21.0 us with the deep ring.)  In the steps:
+        // 7B / TP8 slice at 1024 rows 7.97 -> 7.69 ms, config 4 per rank 13.68 -> 13.54, 7B TP 1 at batch 160-512 -0.3..-1.9 % (r04_split_deep_ab.log)
+        if (splits > 1 && !(forced_st >= 2 && forced_st <= 4))
+            stages = (split_deep && tiles * splits <= 256 && !(wq_bit == 4 && M <= 64)) ? (wq_bit == 0 ? 3 : 4) : 2;
         g2.y = splits;
         // at most one block per CU (<= 256 blocks): 8 waves, 4 of them producers that only issue the ring's LDS-DMA (two waves
         // per SIMD from the one block, the DMA issue runs beside the MFMA stream: wo 59 -> 46 us, w2 120 -> 95 us at

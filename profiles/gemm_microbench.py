@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times pplhip_op_linear on the four linear shapes of a LLaMA-2-7B layer at M = 1024 (W8A16) with HIP events.
-usage: python profiles/gemm_microbench.py [M] [wq 8|4|0] [7b|7b-tp8|13b-tp2|70b-tp8]"""
+usage: python profiles/gemm_microbench.py [M] [wq 8|4|0] [7b|7b-tp8|13b-tp2|70b-tp8] [only this shape: wqkv|wo|w13|w2]"""
 import os, sys
 import numpy as np
 import torch
@@ -17,6 +17,8 @@ SHAPES = {
     "70b-tp8": [("wqkv", 1280, 8192), ("wo", 8192, 1024), ("w13", 7168, 8192), ("w2", 8192, 3584)],
 }
 shapes = SHAPES[MODEL]
+if len(sys.argv) > 4:
+    shapes = [sh for sh in shapes if sh[0] == sys.argv[4]]
 tot_t = tot_f = 0
 for name, N, K in shapes:
     x = (torch.randn(M, K, device="cuda") * 0.5).half()
