@@ -186,12 +186,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const uint16_t* __restrict__ 
 }
 
 // stand-alone launch of the tile body (k_gemm_dev.h)
-template <int WQ, int EPI, int G_ST, int WL, int BM = G_BM>
+template <int WQ, int EPI, int G_ST, int WL, int BM = G_BM, int MAXG = W4_MAXG>
 __global__ __launch_bounds__(WL == 6 ? 768 : (WL == 5 ? 512 : 256)) void gemm_dma_kernel(const uint16_t* __restrict__ x, const void* __restrict__ wv,
                                                              const uint16_t* __restrict__ scale, int64_t M, int N, int K,
                                                              void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles,
                                                              int map_mode, int kt_per_split, float* __restrict__ ws) {
-    __shared__ __attribute__((aligned(16))) char smem[gemm_dma_lds_bytes<WQ, G_ST, BM>()];
+    __shared__ __attribute__((aligned(16))) char smem[gemm_dma_lds_bytes<WQ, G_ST, BM, MAXG>()];
     gemm_dma_body<WQ, EPI, G_ST, WL, BM>(x, wv, scale, M, N, K, yv, ldy, n_tiles, m_tiles, map_mode, kt_per_split, ws, (int)blockIdx.x,
                                      (int)blockIdx.y, (int)gridDim.y, smem);
 }
@@ -885,10 +885,14 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
             if (defer && epi == EPI_F16 && N % 8 == 0 && sp <= 8) { *defer = SplitSlabs{ws, sp, scale, N, M}; return e; }  // the consumer reduces
             return launch_splitk_reduce(s, ws, sp, M, N, scale, y, ldy, epi);
         }
+        // W4 with K slabs of at most 32 tiles (16 quantisation groups): the scale area shrinks from 16 to 4 KiB and three blocks fit a CU
+        static const int w4_sc16 = getenv("PPLHIP_GEMM_W4_SC16") ? atoi(getenv("PPLHIP_GEMM_W4_SC16")) : 1;
+        const bool w4_small_sc = w4_sc16 && wq_bit == 4 && splits > 1 && kt_per <= 32 && wl == 1 && !half && stages == 2;
 #define DMA_LAUNCH(WQ, O32, ST)                                                                                     \
     do { if constexpr (WQ == 8 && ST >= 3) { if (wl == 6) { hipLaunchKernelGGL((gemm_dma_kernel<WQ, O32, ST, 6>), g2, dim3(768), 0, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles, map_mode, kt_per, ws); break; } } \
          if (wl == 5) hipLaunchKernelGGL((gemm_dma_kernel<WQ, O32, ST, 5>), g2, dim3(512), 0, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles, map_mode, kt_per, ws); \
          else if (half) hipLaunchKernelGGL((gemm_dma_kernel<WQ, O32, ST, 1, 64>), g2, block, 0, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles, map_mode, kt_per, ws); \
+         else if (WQ == 4 && ST == 2 && w4_small_sc) hipLaunchKernelGGL((gemm_dma_kernel<WQ, O32, ST, 1, G_BM, 16>), g2, block, 0, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles, map_mode, kt_per, ws); \
          else hipLaunchKernelGGL((gemm_dma_kernel<WQ, O32, ST, 1>), g2, block, 0, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles, map_mode, kt_per, ws); } while (0)
 #define DMA_STAGES(WQ, O32)                                                                                         \
     do { if (stages == 2) DMA_LAUNCH(WQ, O32, 2); else if (stages == 3) DMA_LAUNCH(WQ, O32, 3); else DMA_LAUNCH(WQ, O32, 4); } while (0)

@@ -77,10 +77,12 @@ constexpr int W4_MAXG = 64;  // W4: quantisation groups (of 128 along K) whose s
 //      read / convert / MFMA chains overlap), partial sums added through LDS at the end -- and 4 producers; needs G_ST >= 3;
 // WQ = 8: int8 weights + per-channel scale; WQ = 0: fp16; WQ = 4: int4, group 128
 // LDS bytes gemm_dma_body needs
-template <int WQ, int G_ST, int BM = G_BM>
+// MAXG (W4): quantisation groups whose scales the block keeps in LDS -- W4_MAXG, or 16 for launches whose K slabs span at most 32 tiles
+// (44 instead of 56 KiB with two stages: three blocks per CU instead of two)
+template <int WQ, int G_ST, int BM = G_BM, int MAXG = W4_MAXG>
 constexpr int gemm_dma_lds_bytes() {
     constexpr int WB2 = WQ == 8 ? 2 : (WQ == 4 ? 1 : 4);
-    return G_ST * (BM * G_BK * 2 + G_BN * G_BK * WB2 / 2) + (WQ == 4 ? W4_MAXG * G_BN * 2 : 0);
+    return G_ST * (BM * G_BK * 2 + G_BN * G_BK * WB2 / 2) + (WQ == 4 ? MAXG * G_BN * 2 : 0);
 }
 
 // BM = 64 (WL 1 only): half-height tile for 16 < M <= 64 -- half the activation bytes per stage and half the MFMAs of a 128-row tile whose
