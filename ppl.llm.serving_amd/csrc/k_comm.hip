@@ -117,12 +117,13 @@ __device__ __forceinline__ void add8(float* acc, u32x4 v) {
 // N > 0: compile-time rank count (2, 4, 8); N == 0: any n <= P2P_MAX_RANKS
 template <int N>
 __global__ __launch_bounds__(512) void p2p_allreduce_kernel(P2pPeers peers, int me, int n_rt, size_t data_off, size_t scratch_off,
-                                                            int64_t granules, uint32_t epoch, u64 timeout_ticks, uint32_t* status) {
+                                                            int64_t granules, uint32_t epoch, u64 timeout_ticks, uint32_t* status,
+                                                            size_t flags_off /* channel: a flag set of its own */) {
     const int n = N > 0 ? N : n_rt;
     constexpr int MAXN = N > 0 ? N : P2P_MAX_RANKS;
     const int64_t per = (granules + n - 1) / n;  // slice of rank r: granules [r * per, min((r + 1) * per, granules))
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
-    cross_rank_barrier<false>(peers, me, n, P2P_FLAGS_START, epoch, timeout_ticks, status);
+    cross_rank_barrier<false>(peers, me, n, P2P_FLAGS_START + flags_off, epoch, timeout_ticks, status);
     {   // reduce-scatter into my scratch slice (granule = 16 bytes = 8 fp16)
         const int64_t lo = per * me, hi = (lo + per < granules) ? lo + per : granules;
         char* mine = peers.base[me] + scratch_off;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(512) void p2p_allreduce_kernel(P2pPeers peers, int 
             st_sys16(mine + (g - lo) * 16, __builtin_bit_cast(u32x4, o));
         }
     }
-    cross_rank_barrier<true>(peers, me, n, P2P_FLAGS_MID, epoch, timeout_ticks, status);
+    cross_rank_barrier<true>(peers, me, n, P2P_FLAGS_MID + flags_off, epoch, timeout_ticks, status);
     {   // all-gather: slice r from rank r's scratch -> my buffer (ordinary stores)
         u32x4* out = reinterpret_cast<u32x4*>(peers.base[me] + data_off);
         for (int64_t g = tid; g < per; g += nthr) {
@@ -255,12 +256,13 @@ hipError_t launch_p2p_pattern(hipStream_t s, uint16_t* halfs, int64_t cnt, float
 }
 
 hipError_t launch_p2p_allreduce(hipStream_t s, const P2pPeers& peers, int me, int n, size_t data_off, size_t scratch_off, int64_t count,
-                                uint32_t epoch, uint64_t timeout_ticks, uint32_t* status) {
-    if (n < 2 || n > P2P_MAX_RANKS || count % 8 || data_off % 16 || scratch_off % 16) return hipErrorInvalidValue;
+                                uint32_t epoch, uint64_t timeout_ticks, uint32_t* status, int channel) {
+    if (n < 2 || n > P2P_MAX_RANKS || count % 8 || data_off % 16 || scratch_off % 16 || channel < 0 || channel >= P2P_CHANNELS) return hipErrorInvalidValue;
+    const size_t flags_off = (size_t)channel * P2P_CHANNEL_FLAG_BYTES;
     if (count == 0) return hipSuccess;
     const int64_t granules = count / 8;
     const dim3 grid(grid_for((granules + n - 1) / n)), block(512);
-#define AR(NN) hipLaunchKernelGGL(p2p_allreduce_kernel<NN>, grid, block, 0, s, peers, me, n, data_off, scratch_off, granules, epoch, (u64)timeout_ticks, status)
+#define AR(NN) hipLaunchKernelGGL(p2p_allreduce_kernel<NN>, grid, block, 0, s, peers, me, n, data_off, scratch_off, granules, epoch, (u64)timeout_ticks, status, flags_off)
     if (n == 2) AR(2); else if (n == 4) AR(4); else if (n == 8) AR(8); else AR(0);
 #undef AR
     return hipGetLastError();

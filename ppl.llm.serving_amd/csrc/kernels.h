@@ -152,14 +152,19 @@ constexpr int P2P_MAX_BLOCKS = 64;
 // exchange-region layout (bytes, identical on every rank): flag words first, data buffers after P2P_DATA_START
 constexpr size_t P2P_FLAGS_START = 0;                                         // uint32 [P2P_MAX_BLOCKS][P2P_MAX_RANKS]
 constexpr size_t P2P_FLAGS_MID = (size_t)P2P_MAX_BLOCKS * P2P_MAX_RANKS * 4;  // uint32 [P2P_MAX_BLOCKS][P2P_MAX_RANKS]
+// two channels (flag sets): collectives of different channels may be in flight at the same time (the two half-batches of a two-stream
+// decode step, pplhip.cc run_launches); channel c's words sit P2P_CHANNEL_FLAG_BYTES x c further on
+constexpr int P2P_CHANNELS = 2;
+constexpr size_t P2P_CHANNEL_FLAG_BYTES = (size_t)2 * P2P_MAX_BLOCKS * P2P_MAX_RANKS * 4;
 constexpr size_t P2P_DATA_START = 8192;
+static_assert(P2P_CHANNELS * P2P_CHANNEL_FLAG_BYTES <= P2P_DATA_START, "flag words of every channel in front of the data");
 struct P2pPeers {
     char* base[P2P_MAX_RANKS];  // exchange region of every rank as mapped in this process (base[me] is the local one)
 };
 // all-reduce(sum) of fp16[count] at byte offset data_off of every rank's region (count % 4 == 0); scratch_off: a region
 // offset with room for ceil(count / n) fp16 that no other collective in flight uses
 hipError_t launch_p2p_allreduce(hipStream_t s, const P2pPeers& peers, int me, int n, size_t data_off, size_t scratch_off, int64_t count,
-                                uint32_t epoch, uint64_t timeout_ticks, uint32_t* status);
+                                uint32_t epoch, uint64_t timeout_ticks, uint32_t* status, int channel = 0);   // epochs count per channel
 // rows x row_bytes at src_off of every rank's region (rank r's column block) -> columns [r * row_bytes, ...) of the local
 // [rows, dst_row_bytes] matrix dst (ordinary memory)
 hipError_t launch_p2p_allgather(hipStream_t s, const P2pPeers& peers, int me, int n, size_t src_off, void* dst, int64_t rows,

@@ -55,6 +55,7 @@ struct Rank {
     int global_rank = 0;
     hipStream_t stream = nullptr;
     ncclComm_t comm = nullptr;
+    ncclComm_t comm2 = nullptr;         // the second half-batch's collectives of a two-stream decode step (a communicator serialises its streams)
     hipStream_t comm_stream = nullptr;  // collectives of an overlapped step (pplhip_run)
     // two-stream decode (run_launches, "dual"): the second half of a mid-size pure-decode step runs its layers on stream2, beside the first
     // half on `stream`, with split-K / attention workspaces of its own; ev_fork / ev_join order the two around the step
@@ -126,6 +127,10 @@ struct Rank {
     char* xbase = nullptr;
     size_t xbytes = 0, x_part = 0, x_part2 = 0, x_scratch[2] = {0, 0}, x_local = 0;  // byte offsets inside the region
     uint32_t ar_count = 0;              // all-reduces issued (scratch double buffer)
+    // channel 1 of the direct collectives (second half-batch of a two-stream decode step): flag set, scratch pair, counters of its own
+    size_t x_scratch2[2] = {0, 0};
+    uint32_t ar_count2 = 0, p2p_epoch2 = 0;
+    int channel = 0;                    // which of the two the launches being issued belong to
     P2pPeers peers{};
     bool peer_ipc[P2P_MAX_RANKS] = {};  // peers.base[g] came from hipIpcOpenMemHandle (closed on destroy)
     uint32_t p2p_epoch = 0;
@@ -504,6 +509,7 @@ void pplhip_destroy(pplhip_ctx* c) {
         if (R.stream2) { hipStreamSynchronize(R.stream2); hipStreamDestroy(R.stream2); }
         if (R.ev_fork) hipEventDestroy(R.ev_fork);
         if (R.ev_join) hipEventDestroy(R.ev_join);
+        if (R.comm2) ncclCommDestroy(R.comm2);
         if (R.comm) ncclCommDestroy(R.comm);
         if (R.comm_stream) hipStreamDestroy(R.comm_stream);
         for (int i = 0; i < 2; ++i) {
@@ -635,6 +641,13 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
             NCCLCK(cp, -1, ncclGroupEnd());
         }
         for (int r = 0; r < n; ++r) c->ranks[r].comm = comms[r];
+        if (c->dual_mode) {   // a second communicator over the same ranks for the second stream of a two-stream decode step
+            std::vector<ncclComm_t> comms2(n, nullptr);
+            NCCLCK(cp, -1, ncclGroupStart());
+            for (int r = 0; r < n; ++r) NCCLCK(cp, -1, ncclCommSplit(comms[r], 0, opts->rank_base + r, &comms2[r], nullptr));
+            NCCLCK(cp, -1, ncclGroupEnd());
+            for (int r = 0; r < n; ++r) c->ranks[r].comm2 = comms2[r];
+        }
         c->comm_mode = 1;
     }
 
@@ -705,6 +718,11 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
             R.x_scratch[0] = R.x_part2 + up((size_t)cap_T * hd * 2);          // a rank's reduced slice: <= half the buffer (n >= 2)
             R.x_scratch[1] = R.x_scratch[0] + up((size_t)cap_T * hd + 64);
             R.x_local = R.x_scratch[1] + up((size_t)cap_T * hd + 64);
+            if (c->dual_mode) {
+                R.x_scratch2[0] = R.x_local;
+                R.x_scratch2[1] = R.x_scratch2[0] + up((size_t)cap_T * hd + 64);
+                R.x_local = R.x_scratch2[1] + up((size_t)cap_T * hd + 64);
+            }
             R.xbytes = R.x_local + up((size_t)cap_B * c->vocab_local * 4);
             // FINE-GRAINED device memory: the kind HIP defines as coherent between devices at system scope (what RCCL puts its
             // peer buffers in).  hipDeviceMallocUncached is NOT usable here: with several ranks on one MI355X a kernel reading
@@ -1306,10 +1324,14 @@ static int chunk_allreduce(pplhip_ctx* c, int rank, uint16_t* buf, const Chunk& 
     uint16_t* p = buf + k.t0 * hd;
     auto reduce_on = [&](hipStream_t st) -> int {
         if (c->comm_mode == 2) {
-            HIPCK(c, rank, launch_p2p_allreduce(st, R.peers, R.global_rank, c->tp, (size_t)((char*)p - R.xbase), R.x_scratch[R.ar_count++ & 1],
-                                                k.tn * hd, ++R.p2p_epoch, c->p2p_timeout_ticks, R.p2p_status));
+            if (R.channel == 1)
+                HIPCK(c, rank, launch_p2p_allreduce(st, R.peers, R.global_rank, c->tp, (size_t)((char*)p - R.xbase), R.x_scratch2[R.ar_count2++ & 1],
+                                                    k.tn * hd, ++R.p2p_epoch2, c->p2p_timeout_ticks, R.p2p_status, 1));
+            else
+                HIPCK(c, rank, launch_p2p_allreduce(st, R.peers, R.global_rank, c->tp, (size_t)((char*)p - R.xbase), R.x_scratch[R.ar_count++ & 1],
+                                                    k.tn * hd, ++R.p2p_epoch, c->p2p_timeout_ticks, R.p2p_status));
         } else if (R.comm) {
-            NCCLCK(c, rank, ncclAllReduce(p, p, (size_t)k.tn * hd, ncclFloat16, ncclSum, R.comm, st));
+            NCCLCK(c, rank, ncclAllReduce(p, p, (size_t)k.tn * hd, ncclFloat16, ncclSum, R.channel == 1 ? R.comm2 : R.comm, st));
         }
         return 0;
     };
@@ -1386,16 +1408,19 @@ static int run_launches(pplhip_ctx* c, int rank) {
     // short K loops, the attention launch a few hundred blocks -- so the halves' kernels interleave on the CUs instead of queueing behind each
     // other's ramps and tails, and one half's HBM-bound attention runs beside the other's matrix work.  The halves share nothing but the
     // weights and the KV slab: rows [t0, t0 + tn) of every activation buffer, a split-K workspace and an attention workspace each.  Results
-    // are those of the same rows run as a step of their own.  Not with collectives on a communicator (one stream per communicator),
-    // int8 activations (shared operand buffer), residual dumps or graph capture.
+    // are those of the same rows run as a step of their own.  Under tensor parallelism every half issues its all-reduces on its OWN stream
+    // and channel (direct collectives: a second flag set / scratch pair / epoch counter, k_comm.hip; RCCL: a second communicator over the
+    // same ranks) -- the all-reduce of one half runs beside the other half's matmuls with no hand-off kernels and no extra launches, which
+    // is what the chunked schedule above pays +3.5 ms per 1024-row step for.  Not with int8 activations (shared operand buffer), residual
+    // dumps or graph capture.
     const bool identity_comm = comm && c->comm_mode != 2 && !R.comm;   // ranks emulated on one device (bench.py --emulate-tp)
     bool dual = false;
     if (c->dual_mode && R.stream2 && !ov && nb_decode == B && T == B && B >= c->dual_min_rows && B <= c->dual_max_rows && B >= 2 &&
-        (!comm || identity_comm) && d.act_quant_bit != 8 && !R.dump_dev) {
+        (!comm || identity_comm || c->comm_mode == 2 || (R.comm && R.comm2)) && d.act_quant_bit != 8 && !R.dump_dev) {
         hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(R.stream, &cst);
         if (cst == hipStreamCaptureStatusNone) {
-            const int64_t bm = std::min<int64_t>(B - 1, (B / 2 + 15) / 16 * 16);   // whole 16-row activation sub-tiles in the first half
+            const int64_t bm = B >= 64 ? (B / 2 + 15) / 16 * 16 : B / 2;   // whole 16-row activation sub-tiles in the first half
             ck[0] = Chunk{0, bm, 0, bm, bm};
             ck[1] = Chunk{bm, B - bm, bm, B - bm, B - bm};
             nck = 2;
@@ -1413,11 +1438,13 @@ static int run_launches(pplhip_ctx* c, int rank) {
     auto enter2 = [&]() {
         std::swap(R.stream, R.stream2); std::swap(R.gemm_ws, R.gemm_ws2);
         R.attn_ws += aws_off; R.attn_ws_bytes -= (size_t)aws_off * 4;
+        R.channel = 1;
         std::swap(R.sl_qkv, half2.sl_qkv); std::swap(R.sl_part, half2.sl_part); std::swap(R.sl_part2, half2.sl_part2);
     };
     auto leave2 = [&]() {
         std::swap(R.stream, R.stream2); std::swap(R.gemm_ws, R.gemm_ws2);
         R.attn_ws -= aws_off; R.attn_ws_bytes += (size_t)aws_off * 4;
+        R.channel = 0;
         std::swap(R.sl_qkv, half2.sl_qkv); std::swap(R.sl_part, half2.sl_part); std::swap(R.sl_part2, half2.sl_part2);
     };
     struct Half2Guard {   // (an error return between enter2 and leave2 must not leave the rank on the second stream)

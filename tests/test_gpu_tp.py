@@ -161,6 +161,26 @@ def test_tensor_parallel_group_on_one_device(monkeypatch, tp, mode, overlap):
     g.close()
 
 
+@pytest.mark.parametrize("tp,mode", [(2, 0), (2, 1), (4, 0)])
+def test_tensor_parallel_two_stream_decode(monkeypatch, tp, mode):
+    """PPLHIP_DUAL_STREAM=1 under tensor parallelism: the decode steps run as two half-batches on two streams, each half issuing its
+    all-reduces on its own stream and its own CHANNEL of the direct collectives (flag set, scratch pair, epoch counter: k_comm.hip) -- the
+    all-reduce of one half runs beside the other half's matmuls.  Contiguous and paged cache; against the oracle's tp slices."""
+    m = load_pplhip()
+    monkeypatch.setenv("PPLHIP_DUAL_STREAM", "1")
+    monkeypatch.setenv("PPLHIP_DUAL_MIN_ROWS", "2")
+    monkeypatch.setenv("PPLHIP_TP_OVERLAP", "0")
+    desc = ref.make_desc(hidden_dim=512, intermediate_dim=1024, num_layers=3, num_heads=8, num_kv_heads=8, vocab_size=2048,
+                         max_position=512, cache_quant_bit=8, cache_quant_group=8, cache_layout=3, cache_mode=mode,
+                         page_size=16 if mode else 0, weight_quant_bit=8)
+    g = Group(m, desc, tp, max_batch=16, max_tokens=512, kv_tokens=2048)
+    g.synthetic(31 + tp)
+    rng = np.random.RandomState(tp)
+    prompts = [rng.randint(3, 2048, size=n) for n in (40, 3, 29, 1, 16, 77, 5, 9, 2, 33, 12)]
+    check(f"tp{tp}_tiny_mode{mode}_two_stream", generate(g, prompts, 5), k=1.5)
+    g.close()
+
+
 @pytest.mark.parametrize("tp,overlap", [(2, False), (4, True)])
 def test_tensor_parallel_online_i8i8(monkeypatch, tp, overlap):
     """--quant-method online_i8i8 under tensor parallelism: every rank quantises ITS activation slice rows (the per-token scale of the
