@@ -1,6 +1,7 @@
 // K1 embedding gather, K2 (Skip)RMSNorm (+ last-token gather of K11), K10 SwiGLU -- HBM-bound row kernels.
 // One 256-thread workgroup per row, 16-byte (8 x fp16) accesses per lane, fp32 arithmetic.
 // Semantics: DESIGN.md "numerics"; oracle: ref_embedding / ref_rmsnorm / ref_silu_mul (oracle/llama_ref.c).
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace pplhip {
@@ -21,20 +22,22 @@ hipError_t launch_embedding(hipStream_t s, const int64_t* token_ids, const uint1
 }
 
 // Each thread keeps up to MAXC chunks of its row in registers (hidden <= 256*8*MAXC); larger rows re-read.
-template <int MAXC>
-__global__ __launch_bounds__(256) void rmsnorm_kernel(const uint4* x /* may alias residual_out */, const uint4* __restrict__ skip,
+// NT threads per row: 256, or -- steps of a few hundred rows at most, where the launch is one block per CU or less and a row is a chain of
+// latencies (load, reduce, barrier, store) rather than bandwidth -- 512 / 1024 with one chunk per thread (launch_rmsnorm)
+template <int MAXC, int NT = 256>
+__global__ __launch_bounds__(NT) void rmsnorm_kernel(const uint4* x /* may alias residual_out */, const uint4* __restrict__ skip,
                                                       const uint4* __restrict__ w, float eps, int chunks, int hidden,
                                                       const int64_t* __restrict__ gather, uint4* __restrict__ out,
                                                       uint4* residual_out, int8_t* __restrict__ qout, float* __restrict__ sx, SplitSlabs sl) {
-    __shared__ float red[4];
-    __shared__ float redq[4];
+    __shared__ float red[NT / 64];
+    __shared__ float redq[NT / 64];
     const int64_t r = blockIdx.x;
     const int64_t src = gather ? gather[r + 1] - 1 : r;
     float v[MAXC][8];
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
-        const int c = threadIdx.x + i * 256;
+        const int c = threadIdx.x + i * NT;
         if (c < chunks) {
             unpack8(x[src * chunks + c], v[i]);
             if (skip || sl.splits) {
@@ -55,18 +58,20 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint4* x /* may alia
     uint4 wraw[MAXC];
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
-        const int c = threadIdx.x + i * 256;
+        const int c = threadIdx.x + i * NT;
         wraw[i] = c < chunks ? w[c] : make_uint4(0, 0, 0, 0);
     }
     ss = wave_sum(ss);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
     __syncthreads();
     ss = red[0] + red[1] + red[2] + red[3];
+#pragma unroll
+    for (int wv = 4; wv < NT / 64; ++wv) ss += red[wv];
     const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
     if (!qout) {
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
-            const int c = threadIdx.x + i * 256;
+            const int c = threadIdx.x + i * NT;
             if (c < chunks) {
                 float wf[8], o[8];
                 unpack8(wraw[i], wf);
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint4* x /* may alia
     float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
-        const int c = threadIdx.x + i * 256;
+        const int c = threadIdx.x + i * NT;
         if (c < chunks) {
             float wf[8];
             unpack8(wraw[i], wf);
@@ -98,11 +103,13 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint4* x /* may alia
     if ((threadIdx.x & 63) == 0) redq[threadIdx.x >> 6] = amax;
     __syncthreads();
     amax = fmaxf(fmaxf(redq[0], redq[1]), fmaxf(redq[2], redq[3]));
+#pragma unroll
+    for (int wv = 4; wv < NT / 64; ++wv) amax = fmaxf(amax, redq[wv]);
     const float qinv = amax > 0.f ? 127.0f / amax : 0.f;
     if (threadIdx.x == 0) sx[r] = amax / 127.0f;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
-        const int c = threadIdx.x + i * 256;
+        const int c = threadIdx.x + i * NT;
         if (c < chunks) {
             uint32_t lo = 0, hi = 0;
 #pragma unroll
@@ -131,6 +138,19 @@ hipError_t launch_rmsnorm(hipStream_t s, const uint16_t* x, const uint16_t* skip
 #define RMS_LAUNCH(MC)                                                                                              \
     hipLaunchKernelGGL(rmsnorm_kernel<MC>, g, b, 0, s, (const uint4*)x, (const uint4*)skip, (const uint4*)w, eps,   \
                        chunks, hidden, gather_seq_starts, (uint4*)out, (uint4*)residual_out, qout, sx, sl)
+    // few rows of a wide model (decode steps of 5..512 rows at hidden >= 4096): one chunk per thread on 512 / 1024 threads -- every load of
+    // the row is in flight at once.  (Up to 4 rows stay on the 256-thread form: the fused GEMV norm of k_gemv.hip restates ITS summation order.)
+    // OPT-IN (PPLHIP_RMSNORM_WIDE_MAX_ROWS=512): -1.9 % on config 4's per-rank step and -0.4..-1.7 % on 7B steps of 8-512 rows, but the other
+    // summation order of the sum of squares moves the 70B / TP8 W4A16 parity case (tests/test_gpu_tp.py, an ill-conditioned synthetic geometry:
+    // profiles/r04_late_experiments.md sections 4 and 7) from < 1.5e-3 to 1.66e-3 of max|logit| -- over its fixed cap, so it is not the default
+    static const int wide_rows = getenv("PPLHIP_RMSNORM_WIDE_MAX_ROWS") ? atoi(getenv("PPLHIP_RMSNORM_WIDE_MAX_ROWS")) : 0;
+    if (rows > 4 && rows <= wide_rows && chunks >= 512 && chunks <= 1024 && chunks % 64 == 0) {
+        if (chunks <= 512) hipLaunchKernelGGL((rmsnorm_kernel<1, 512>), g, dim3(512), 0, s, (const uint4*)x, (const uint4*)skip, (const uint4*)w, eps,
+                                              chunks, hidden, gather_seq_starts, (uint4*)out, (uint4*)residual_out, qout, sx, sl);
+        else hipLaunchKernelGGL((rmsnorm_kernel<1, 1024>), g, dim3(1024), 0, s, (const uint4*)x, (const uint4*)skip, (const uint4*)w, eps,
+                                chunks, hidden, gather_seq_starts, (uint4*)out, (uint4*)residual_out, qout, sx, sl);
+        return hipGetLastError();
+    }
     if (chunks <= 256) RMS_LAUNCH(1);
     else if (chunks <= 512) RMS_LAUNCH(2);
     else if (chunks <= 1024) RMS_LAUNCH(4);
