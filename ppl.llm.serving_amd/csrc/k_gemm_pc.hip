@@ -1,29 +1,31 @@
-// W4A16 (group 128) linear layers at a few hundred rows (round 5): converter waves beside MFMA waves.
+// W4A16 (group 128) linear layers at a few hundred rows (round 5): 128 x 64 tiles, DMA waves beside MFMA waves, a rolling register pipeline.
 //
 // Why another tile kernel.  At M = 256 (config 4: LLaMA-2-70B W4A16, TP 8, batch 256) the 128 x 128 ring kernel of k_gemm_dev.h ran the
 // layer's four GEMMs at 19 % of the MFMA peak (profiles/r04_late_experiments.md 3): 112 / 20 / 128 output tiles do not fill 256 CUs, so
 // every launch was cut into K slabs (fp32 partial sums of the whole output written and read back: 2.8 x the algorithmic bytes on w13,
 // 4 x on wo) and inside a wave each K tile was a serial wait -> barrier -> DMA issue -> int4 conversion -> fragment reads -> MFMA chain.
-// This kernel changes the decomposition and the roles:
+// This kernel changes the decomposition and the schedule:
 //   * block tile 128 (m) x 64 (n): 224 / 256 / 256 blocks for w13 / wo / w2 of that layer -- one per CU, NO K slabs, outputs written once
-//     in fp16 (wqkv, 40 tiles, keeps slabs that RoPE + KV write sums anyway);
-//   * 8 waves, two per SIMD with different jobs.  Waves 4..7 (producers / converters) own the data movement: the activation tiles go
-//     global -> LDS by DMA into a 4-stage ring; the int4 weights of a 128-deep super-tile (= one quantisation group; 64 rows x 64 bytes,
-//     16 rows per wave, a lane's 16 bytes = 32 nibbles of one row) and their group scales go global -> LDS by DMA into a raw ring five
-//     super-tiles deep (HBM latency is hidden by depth, not by occupancy), are read back by the lane that fetched them, converted ONCE
-//     per block to fp16(q * scale) and written as MFMA-ready fp16 rows into a double-buffered weight image;
-//   * waves 0..3 (consumers, 2 (n) x 2 (m), each 32 (n) x 64 (m)) do nothing but read fragments (12 ds_read_b128 per K tile, a whole tile
-//     ahead of their use, double-buffered in registers) and issue v_mfma_f32_32x32x16_f16: no conversion, no address arithmetic, no
-//     vmcnt in their instruction stream.  One s_barrier per 64-deep K tile.
-// LDS (121 KiB, one block per CU): X ring 4 x 16 KiB [128 rows][64 fp16], 16-byte chunk q of row r at position q ^ ((r >> 1) & 7);
-// fp16 weights 2 super-tiles x 2 K tiles x 8 KiB [64 rows][64 fp16], chunk q of row r of K tile t at q ^ ((r >> 1) & 7) ^ 2 (t & 1)
-// (conflict-free fragment reads AND conflict-free converter writes); raw ring 5 x 4 KiB; scale ring 5 x 1 KiB.
-// Every memory operation of the producers is an LDS-DMA issued from inline asm (no VGPR destinations: nothing for hipcc to mis-wait),
-// counted with s_waitcnt vmcnt(N); N is derived below from the fixed issue order, and the tail re-issues clamped loads so that the
-// counts stay static.
-// Numerics: the dequantised weight is the fp16 number fp16(q * scale) (cvt_i4x8_f16, as every W4 kernel here), fp32 accumulation in k
-// order, one rounding of the sum to fp16.  Oracle: ref_linear_fwd (oracle/llama_ref.c).  Reference call site: the model's linear nodes
-// behind runtime->Run() (/root/reference/src/engine/llm_engine.cc:113-116) under --quant-method of
+//     in fp16 through LDS (whole 128-byte rows); wqkv (40 tiles) keeps slabs that RoPE + KV write sums anyway;
+//   * a K step is a SUPER-TILE of 128 = one quantisation group: one s_barrier per 128 deep (the barrier round trip was ~150 cycles of a
+//     64-deep tile whose MFMAs take 256, profiles/r05_w4_pc_experiments.md);
+//   * waves 4..7 (producers) only issue LDS-DMA: the activation super-tile (two [128 rows][64 fp16] tiles, 8 one-KiB pieces per wave)
+//     into a 4-slot ring, the raw int4 weights (64 rows x 64 bytes, one piece per wave) and their group scales into 4-slot rings;
+//   * waves 0..3 (consumers, 2 (n) x 2 (m), each 32 (n) x 64 (m) on v_mfma_f32_32x32x16_f16) keep ONE register set of fragments that
+//     rolls: behind the two MFMAs of k-step ks of super-tile s, the activation fragments of k-step ks of super-tile s + 1 are read into
+//     the registers those MFMAs just released, and the int4 weights of that k-step (8 nibbles per lane, read a super-tile earlier) are
+//     converted to fp16(q x scale) in registers (cvt_i4x8_f16) -- no fp16 weight image in LDS, no converter wave on the critical path
+//     (the first form of this kernel had both: its converter waves needed ~840 cycles per 64-deep tile, ibid.).  A lane half h multiplies
+//     k = 64 h + 8 ks .. + 8 of the super-tile in k-step ks (both operands use the same permutation of the contraction index), so that
+//     a lane's 32 weight bytes are contiguous and its activation chunk ks sits in the 64-deep tile h.
+// LDS (148 KiB, one block per CU): X ring 4 x 32 KiB, 16-byte chunk q of row r of a tile at position q ^ ((r >> 1) & 7) (conflict-free
+// ds_read_b128 by 32 rows); raw ring 4 x 4 KiB [64 rows][64 B], chunk c of row r at c ^ ((r >> 2) & 3); scale ring 4 x 1 KiB (one
+// dword per producer lane).  Every global access of the producers is an LDS-DMA issued from inline asm (no VGPR destinations: nothing
+// for hipcc to mis-wait), counted with s_waitcnt vmcnt(N); N follows from the fixed issue order, and the tail re-issues clamped loads
+// so that the counts stay static.
+// Numerics: the dequantised weight is the fp16 number fp16(q * scale) (cvt_i4x8_f16, as every W4 kernel here), fp32 accumulation, one
+// rounding of the sum to fp16.  Oracle: ref_linear_fwd (oracle/llama_ref.c).  Reference call site: the model's linear nodes behind
+// runtime->Run() (/root/reference/src/engine/llm_engine.cc:113-116) under --quant-method of
 // /root/reference/src/backends/cuda/resource_manager.cc:49-56.
 #include <stdlib.h>
 
@@ -36,14 +38,12 @@ namespace {
 typedef float f16v __attribute__((ext_vector_type(16)));
 
 constexpr int PC_BM = 128, PC_BN = 64;
-constexpr int PC_XB = PC_BM * 64 * 2;   // activation bytes per K tile: 16 KiB
-constexpr int PC_WB = PC_BN * 64 * 2;   // converted weight bytes per K tile: 8 KiB
-constexpr int PC_ST = 4;                // activation ring, K tiles
-constexpr int PC_PD = 4;                // raw-weight prefetch distance, super-tiles
-constexpr int PC_RD = PC_PD + 1;        // raw / scale ring slots
+constexpr int PC_XT = PC_BM * 64 * 2;   // one 64-deep activation tile: 16 KiB
+constexpr int PC_XB = 2 * PC_XT;        // activation bytes per super-tile: 32 KiB
+constexpr int PC_NS = 4;                // ring slots (activations, raw weights, scales), super-tiles
 constexpr int PC_RAWB = PC_BN * 64;     // raw int4 bytes per super-tile: 4 KiB (1 KiB per producer wave)
 constexpr int PC_SCB = 1024;            // scale slot: one dword per producer lane
-constexpr int PC_LDS = PC_ST * PC_XB + 4 * PC_WB + PC_RD * (PC_RAWB + PC_SCB);
+constexpr int PC_LDS = PC_NS * (PC_XB + PC_RAWB + PC_SCB);
 static_assert(PC_LDS <= 160 * 1024, "one block per CU");
 
 // LDS-DMA, 16 / 4 bytes per lane: wave-uniform 64-bit base in SGPRs + per-lane 32-bit byte offset (the per-tile address update is
@@ -61,6 +61,14 @@ __device__ __forceinline__ void glds4_s(uint32_t voff, const void* sbase, uint32
                  : "=&s"(keep)
                  : "v"(voff), "s"(sbase), "s"(lds_wave_base)
                  : "memory");
+}
+typedef uint32_t pc_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 lds_ld16(uint32_t a) {   // ds_read_b128 from an LDS byte address
+    const pc_u32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) pc_u32x4*>((uintptr_t)a);
+    return __builtin_bit_cast(uint4, v);
+}
+__device__ __forceinline__ uint32_t lds_ld4(uint32_t a) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>((uintptr_t)a);
 }
 
 #ifdef PC_ABLATE_BUILD
@@ -83,9 +91,8 @@ __global__ __launch_bounds__(512) void gemm_w4_pc_kernel(const uint16_t* __restr
 #endif
     extern __shared__ __attribute__((aligned(128))) char smem_pc[];  // ONE shared object (a second one de-pipelines DMA kernels)
     char* const Xs = smem_pc;
-    char* const Wf = smem_pc + PC_ST * PC_XB;
-    char* const Raw = Wf + 4 * PC_WB;
-    char* const Scl = Raw + PC_RD * PC_RAWB;
+    char* const Raw = smem_pc + PC_NS * PC_XB;
+    char* const Scl = Raw + PC_NS * PC_RAWB;
 
     // XCD id % 8 owns the weight tiles n == id (mod 8); the m tiles of a weight tile are neighbours on that XCD (its L2 serves the second)
     const int id = blockIdx.x;
@@ -101,172 +108,167 @@ __global__ __launch_bounds__(512) void gemm_w4_pc_kernel(const uint16_t* __restr
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+    // Barrier B_j (j = 0 .. nst) "super-tile j is published": the producers have seen the activations of super-tile j and the raw
+    // weights + scales of super-tile j + 1 land; the consumers have every fragment of super-tile j - 1 in registers (so the slots of
+    // activations j - 1 and raw weights j are free behind it).
     if (wave >= 4) {
         // ------------------------------------------------------------------------------------------------------------------------
-        // producer / converter wave pw: activation pieces P = pw + 4 j (8 rows x 128 B each) of every K tile; weight rows 16 pw .. + 16
+        // producer wave pw: activation pieces P = pw + 4 i (8 rows x 128 B) of both tiles of every super-tile; weight rows 16 pw .. + 16
         // ------------------------------------------------------------------------------------------------------------------------
         const int pw = wave - 4;
         uint32_t xoff[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = 8 * (pw + 4 * j) + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+        for (int i = 0; i < 4; ++i) {
+            const int row = 8 * (pw + 4 * i) + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
             int64_t m = m0 + row;
             if (m >= M) m = M - 1;                     // rows past M are never stored
-            xoff[j] = (uint32_t)((m * K + c * 8) * 2);
+            xoff[i] = (uint32_t)((m * K + c * 8) * 2);
         }
-        const int seg = lane & 3, R = 16 * pw + (lane >> 2);   // this lane's weight row inside the tile, its 32-nibble segment of a super-tile
+        const int R = 16 * pw + (lane >> 2);           // this lane's weight row inside the tile; it fetches LDS chunk position lane & 3 of it
         int n = n0 + R;
         if (n >= N) n = N - 1;
-        const uint32_t woff = (uint32_t)((int64_t)n * (K >> 1) + seg * 16);
+        const uint32_t woff = (uint32_t)((int64_t)n * (K >> 1) + (((lane & 3) ^ ((R >> 2) & 3)) << 4));
         const uint32_t nG = (uint32_t)n * (uint32_t)G;          // index of the row's first group scale
         const uint32_t xdst = __builtin_amdgcn_readfirstlane(lds_addr(Xs) + pw * 1024);
         const uint32_t rdst = __builtin_amdgcn_readfirstlane(lds_addr(Raw) + pw * 1024);
         const uint32_t sdst = __builtin_amdgcn_readfirstlane(lds_addr(Scl) + pw * 256);
-        const char* const xb = reinterpret_cast<const char*>(x) + (int64_t)g0 * 256;   // this split's first K tile
-        const int kt_last = 2 * nst - 1;
-        // converter addresses: chunk j of this lane's segment goes to K tile kt = seg >> 1, position ((seg & 1) * 4 + j) ^ f(R) ^ 2 kt
-        const int kt_l = seg >> 1, bp = ((seg & 1) * 4) ^ ((R >> 1) & 7) ^ (2 * kt_l);
-        char* const wdst = Wf + kt_l * PC_WB + R * 128;
-        const char* const rsrc = Raw + pw * 1024 + lane * 16;
-        const char* const ssrc = Scl + pw * 256 + lane * 4;
+        const char* const xb = reinterpret_cast<const char*>(x) + (int64_t)g0 * 256;   // this split's first super-tile
 
-        auto issue_x = [&](int t) {                    // K tile t of this split -> ring stage t % PC_ST (past the end: tile kt_last again)
-            if ((ABL & 4) && t >= PC_ST) return;
-            const int tc = t < kt_last ? t : kt_last;
-            const char* base = xb + (int64_t)tc * 128;
-            const uint32_t d = xdst + (uint32_t)(t & (PC_ST - 1)) * PC_XB;
+        // DMA operations per super-tile and wave: raw weights (1), scales (1), activations (tile 0: 4 pieces, tile 1: 4 pieces).
+        // Super-tiles past the end re-load the last one (into slots nobody reads any more): the wait counts stay static.
+        auto issue_r = [&](int j) {
+            if ((ABL & 8) && j >= PC_NS) return;
+            const int g = g0 + (j < nst ? j : nst - 1), sl = j & (PC_NS - 1);
+            glds16_s(woff, w + (int64_t)g * 64, rdst + sl * PC_RAWB);
+            glds4_s((2u * (nG + (uint32_t)g)) & ~3u, scale, sdst + sl * PC_SCB);
+        };
+        auto issue_x = [&](int j) {
+            if ((ABL & 4) && j >= PC_NS - 1) return;
+            const char* base = xb + (int64_t)(j < nst ? j : nst - 1) * 256;
+            const uint32_t d = xdst + (uint32_t)(j & (PC_NS - 1)) * PC_XB;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) glds16_s(xoff[j], base, d + j * 4096);
-        };
-        auto issue_r = [&](int s, int rs) {            // raw weights + scales of super-tile s -> raw slot rs
-            if ((ABL & 8) && s > PC_PD) return;
-            const int g = g0 + (s < nst ? s : nst - 1);
-            glds16_s(woff, w + (int64_t)g * 64, rdst + rs * PC_RAWB);
-            glds4_s((2u * (nG + (uint32_t)g)) & ~3u, scale, sdst + rs * PC_SCB);
-        };
-        uint4 raw;                                     // the super-tile being converted: half of it in front of each of the two barriers
-        h2 sc2;
-        char* cd;
-        auto convert_a = [&](int s, int rs) {          // raw slot rs (super-tile s) -> fp16 image (s & 1), chunks 0 and 1
-            if (ABL & 2) return;
-            const int g = g0 + s;
-            raw = *reinterpret_cast<const uint4*>(rsrc + rs * PC_RAWB);
-            const _Float16 sv = *reinterpret_cast<const _Float16*>(ssrc + rs * PC_SCB + ((nG + (uint32_t)g) & 1u) * 2);
-            sc2 = h2{sv, sv};
-            cd = wdst + (s & 1) * (2 * PC_WB);
-            *reinterpret_cast<uint4*>(cd + ((bp ^ 0) << 4)) = __builtin_bit_cast(uint4, cvt_i4x8_f16(raw.x, sc2));
-            *reinterpret_cast<uint4*>(cd + ((bp ^ 1) << 4)) = __builtin_bit_cast(uint4, cvt_i4x8_f16(raw.y, sc2));
-        };
-        auto convert_b = [&]() {                       // chunks 2 and 3
-            if (ABL & 2) return;
-            *reinterpret_cast<uint4*>(cd + ((bp ^ 2) << 4)) = __builtin_bit_cast(uint4, cvt_i4x8_f16(raw.z, sc2));
-            *reinterpret_cast<uint4*>(cd + ((bp ^ 3) << 4)) = __builtin_bit_cast(uint4, cvt_i4x8_f16(raw.w, sc2));
-        };
-
-        // prologue.  Issue order (what the counts below are derived from): R(0) S(0) .. R(PD) S(PD), X(0) X(1) X(2);
-        // then per iteration s: X(2s+3) [4], R(s+1+PD) S(s+1+PD) [2], X(2s+4) [4].
+            for (int i = 0; i < 4; ++i) glds16_s(xoff[i], base, d + i * 4096);
 #pragma unroll
-        for (int s = 0; s <= PC_PD; ++s) issue_r(s, s);
-        issue_x(0); issue_x(1); issue_x(2);
-        PC_VMCNT(2 * PC_PD + 12);                      // R(0), S(0) landed
-        convert_a(0, 0);
-        convert_b();
-        PC_VMCNT(8);                                   // X(0) landed
-        PC_LGKM0();
-        __builtin_amdgcn_s_barrier();                  // B_0: tile 0 published
-        int rs_new = 0;                                // raw slot of super-tile s + 1 + PD == slot of super-tile s
-        int rs_cvt = 1;                                // raw slot of super-tile s + 1
-#define PC_ITER(S, NR, NX1)                                                                                              \
-    do {                                                                                                                 \
-        issue_x(2 * (S) + 3);                                                                                            \
-        issue_r((S) + 1 + PC_PD, rs_new);                                                                               \
-        PC_VMCNT(NR);                                  /* R(s+1), S(s+1) landed */                                       \
-        if ((S) + 1 < nst) convert_a((S) + 1, rs_cvt);                                                                   \
-        PC_VMCNT(NX1);                                 /* X(2s+1) landed */                                              \
-        __builtin_amdgcn_s_barrier();                  /* B_{2s+1} */                                                    \
-        issue_x(2 * (S) + 4);                                                                                            \
-        if ((S) + 1 < nst) convert_b();                                                                                  \
-        if ((S) + 1 < nst) PC_VMCNT(10); else PC_VMCNT(0);   /* X(2s+2) landed; last iteration: everything (the epilogue reuses the ring) */ \
-        PC_LGKM0();                                    /* the converted super-tile is written */                          \
-        __builtin_amdgcn_s_barrier();                  /* B_{2s+2} */                                                    \
-        rs_new = rs_new == PC_RD - 1 ? 0 : rs_new + 1;                                                                   \
-        rs_cvt = rs_cvt == PC_RD - 1 ? 0 : rs_cvt + 1;                                                                   \
-    } while (0)
-        // the first PD iterations wait for loads of the prologue: R(s+1) has 2 (PD - s - 1) + 12 + 10 s + 6 younger operations
-        static_assert(PC_PD == 4, "peeled iterations below");
-        PC_ITER(0, 2 * PC_PD + 16, 10);
-        if (nst > 1) PC_ITER(1, 2 * PC_PD + 24, 12);
-        if (nst > 2) PC_ITER(2, 2 * PC_PD + 32, 12);
-        if (nst > 3) PC_ITER(3, 2 * PC_PD + 40, 12);
-        for (int s = PC_PD; s < nst; ++s) PC_ITER(s, 10 * PC_PD, 12);
-#undef PC_ITER
+            for (int i = 0; i < 4; ++i) glds16_s(xoff[i], base + 128, d + PC_XT + i * 4096);
+        };
+        // prologue: R S X(0) | R S X(1) | R S X(2) | R S (3); iteration j then issues R S (j + 4), X(j + 3)
+        issue_r(0); issue_x(0); issue_r(1); issue_x(1); issue_r(2); issue_x(2); issue_r(3);
+        PC_VMCNT(2 + 10);                              // x(0) [and raw(0), raw(1)] landed: younger = raw(3) (2) + all of super-tile 2 (10)
+        __builtin_amdgcn_s_barrier();                  // B_0
+        __builtin_amdgcn_s_barrier();                  // B_0': the consumers hold super-tile 0 and raw(1) in registers (raw slot 0 is free)
+        for (int j = 0; j < nst; ++j) {
+            // behind B_j: raw slot j % 4 and activation slot (j - 1) % 4 are free
+            issue_r(j + PC_NS);
+            issue_x(j + PC_NS - 1);
+            // x(j + 1) and raw(j + 2) landed.  x(j + 1) was issued two iterations ago (in the prologue for j < 2); younger than its last
+            // piece: j = 0: R S of super-tile 3 (2) + x(2)'s group (8) + this iteration (10) = 20 -- and 20 in the steady state as well
+            if (j + 1 < nst) PC_VMCNT(20); else PC_VMCNT(0);   // last iteration: everything (the epilogue reuses the rings)
+            __builtin_amdgcn_s_barrier();              // B_{j+1}
+        }
     } else {
         // ------------------------------------------------------------------------------------------------------------------------
-        // consumer wave (wn, wm): 32 weight rows x 64 activation rows; fragments of K tile t + 1 are read while tile t is multiplied
+        // consumer wave (wn, wm): 32 weight rows x 64 activation rows
         // ------------------------------------------------------------------------------------------------------------------------
         const int wn = wave & 1, wm = wave >> 1;
-        const int r = lane & 31, hh = lane >> 5, sw = (hh ^ ((r >> 1) & 7)) << 4;
-        const char* const xrow = Xs + (64 * wm + r) * 128;
-        const char* const wrow = Wf + (32 * wn + r) * 128;
+        const int r = lane & 31, hh = lane >> 5;
+        // activation fragment (ks, jm) of ring slot sl: tile hh of the super-tile, row 64 wm + 32 jm + r, chunk position ks ^ f(r).
+        // Slots 2 and 3 lie beyond the 16-bit offset field of ds_read: a second base
+        const uint32_t xa = lds_addr(Xs) + hh * PC_XT + (64 * wm + r) * 128 + (((r >> 1) & 7) << 4);
+        uint32_t xlo[8], xhi[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) { xlo[ks] = xa ^ (uint32_t)(ks << 4); xhi[ks] = xlo[ks] + 2 * PC_XB; }
+        const int R = 32 * wn + r;
+        // raw weights: this lane's 32 bytes = chunks 2 hh, 2 hh + 1 of row R, stored at positions c ^ ((R >> 2) & 3)
+        const uint32_t ra0 = lds_addr(Raw) + R * 64 + (((2 * hh) ^ ((R >> 2) & 3)) << 4);
+        const uint32_t ra1 = lds_addr(Raw) + R * 64 + (((2 * hh + 1) ^ ((R >> 2) & 3)) << 4);
+        int nrow = n0 + R;
+        if (nrow >= N) nrow = N - 1;
+        const uint32_t nG = (uint32_t)nrow * (uint32_t)G;
+        const uint32_t sa = lds_addr(Scl) + (R >> 4) * 256 + (R & 15) * 16;   // the dword its row's producer lanes fetched
+
         f16v acc0, acc1;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
-        uint4 fw[2][4], fx[2][4][2];
-        // phase p = t % 4 fixes every LDS offset of tile t: ring stage p, weight image (p >> 1) & 1, K tile p & 1 of it
-#define PC_READ(BUF, P)                                                                                                   \
+        uint4 xf[8][2];                                // activation fragments of the super-tile being multiplied (rolling)
+        h8 wf[8];                                      // its converted weight fragments (rolling)
+        uint4 rwa, rwb;                                // raw weights of the NEXT super-tile (words 0..3, 4..7 = its k-steps)
+        uint32_t scw;                                  // ... and the dword that holds its scale
+
+#define PC_XADDR(SL, KS, JM) (((SL) < 2 ? xlo[KS] : xhi[KS]) + (uint32_t)(((SL) & 1) * PC_XB + (JM) * 4096))
+#define PC_RAW_READ(SL)                                                                                                   \
     do {                                                                                                                  \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                                \
-            fw[BUF][ks] = *reinterpret_cast<const uint4*>(wrow + (((P) >> 1) & 1) * (2 * PC_WB) + ((P) & 1) * PC_WB +    \
-                                                          (sw ^ (ks << 5) ^ (((P) & 1) << 5)));                          \
-            fx[BUF][ks][0] = *reinterpret_cast<const uint4*>(xrow + (P) * PC_XB + (sw ^ (ks << 5)));                      \
-            fx[BUF][ks][1] = *reinterpret_cast<const uint4*>(xrow + (P) * PC_XB + 32 * 128 + (sw ^ (ks << 5)));          \
-        }                                                                                                                 \
+        rwa = lds_ld16(ra0 + (SL) * PC_RAWB);                                                                             \
+        rwb = lds_ld16(ra1 + (SL) * PC_RAWB);                                                                             \
+        scw = lds_ld4(sa + (SL) * PC_SCB);                                                                                \
     } while (0)
-#define PC_MMA(BUF)                                                                                                       \
-    do {                                                                                                                  \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                                \
-            const h8 a = __builtin_bit_cast(h8, fw[BUF][ks]);                                                             \
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(h8, fx[BUF][ks][0]), acc0, 0, 0, 0);      \
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(h8, fx[BUF][ks][1]), acc1, 0, 0, 0);      \
-        }                                                                                                                 \
-    } while (0)
+        auto scale_of = [&](int g) {                   // the group scale in scw: element nG + g of the scale matrix
+            const uint32_t v = ((nG + (uint32_t)g) & 1u) ? (scw >> 16) : (scw & 0xffffu);
+            const _Float16 sv = __builtin_bit_cast(_Float16, (uint16_t)v);
+            return h2{sv, sv};
+        };
+
+        // prologue: everything of super-tile 0, the raw weights of super-tile 1
+        __builtin_amdgcn_s_barrier();                  // B_0
+        PC_RAW_READ(0);
+        {
+            const h2 sc2 = scale_of(g0);
+            const uint32_t wv[8] = {rwa.x, rwa.y, rwa.z, rwa.w, rwb.x, rwb.y, rwb.z, rwb.w};
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                wf[ks] = cvt_i4x8_f16(wv[ks], sc2);
+                xf[ks][0] = lds_ld16(PC_XADDR(0, ks, 0));
+                xf[ks][1] = lds_ld16(PC_XADDR(0, ks, 1));
+            }
+        }
+        PC_RAW_READ(1);
+        PC_LGKM0();
+        __builtin_amdgcn_s_barrier();                  // B_0'
+
+        // phase of super-tile s (slot p = s % 4): MFMAs of s; behind k-step ks its registers take k-step ks of super-tile s + 1 (slot p + 1);
+        // the raw weights of s + 2 (slot p + 2) are read at the end
 #define PC_PHASE(P)                                                                                                       \
     do {                                                                                                                  \
-        PC_LGKM0();                                    /* my reads of tile t are complete: its stage may be refilled */   \
-        __builtin_amdgcn_s_barrier();                  /* B_{t+1} */                                                      \
-        __builtin_amdgcn_sched_barrier(0);             /* (hipcc otherwise hoists the next phase's wait + barrier above these MFMAs) */ \
-        if (!(ABL & 16)) PC_READ(((P) + 1) & 1, ((P) + 1) & 3);         /* (unconditional: behind a branch hipcc waits lgkmcnt(0) at the join; past the last tile the reads fetch stale bytes that nobody uses) */ \
-        if (!(ABL & 1)) PC_MMA((P) & 1);                                                                                  \
-        /* the twelve fragment reads in the shadow of the first two MFMAs (left alone, hipcc re-uses the registers of issued MFMAs and */ \
-        /* the reads land only at the end of the phase, in front of the wait) */                                         \
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                                \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                \
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                                \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                \
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                                \
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                                                \
-        asm volatile("" : "+v"(acc0), "+v"(acc1));     /* the MFMAs stay in their phase (an MFMA is register-only: neither "memory" nor sched_barrier holds it) */ \
+        PC_LGKM0();                                    /* every read of super-tile s + 1's predecessors has landed */     \
+        __builtin_amdgcn_s_barrier();                  /* B_{s+1} */                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+        const h2 sc2 = scale_of(g0 + s0 + (P) + 1);                                                                       \
+        const uint32_t wv[8] = {rwa.x, rwa.y, rwa.z, rwa.w, rwb.x, rwb.y, rwb.z, rwb.w};                                  \
+        _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                                \
+            if (!(ABL & 1)) {                                                                                             \
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], __builtin_bit_cast(h8, xf[ks][0]), acc0, 0, 0, 0);  \
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], __builtin_bit_cast(h8, xf[ks][1]), acc1, 0, 0, 0);  \
+            }                                                                                                             \
+            if (!(ABL & 16)) {                                                                                            \
+                xf[ks][0] = lds_ld16(PC_XADDR(((P) + 1) & 3, ks, 0));                                                     \
+                xf[ks][1] = lds_ld16(PC_XADDR(((P) + 1) & 3, ks, 1));                                                     \
+            }                                                                                                             \
+            if (!(ABL & 2)) wf[ks] = cvt_i4x8_f16(wv[ks], sc2);                                                           \
+        }                                                                                                                 \
+        PC_RAW_READ(((P) + 2) & 3);                                                                                       \
+        _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                                \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   /* two MFMAs */                                          \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   /* the two fragment reads that refill their registers */ \
+            __builtin_amdgcn_sched_group_barrier(0x002, 20, 0);  /* the conversion of the same k-step of the next super-tile */ \
+        }                                                                                                                 \
+        asm volatile("" : "+v"(acc0), "+v"(acc1));     /* the MFMAs stay in their phase (register-only: "memory" does not hold them) */ \
         __builtin_amdgcn_sched_barrier(0);                                                                                \
     } while (0)
-        const int kt_all = 2 * nst;
-        __builtin_amdgcn_s_barrier();                  // B_0
-        PC_READ(0, 0);
-        int t0 = 0;
-        for (; t0 + 4 <= kt_all; t0 += 4) {
+        int s0 = 0;
+        for (; s0 + 4 <= nst; s0 += 4) {
             PC_PHASE(0);
             PC_PHASE(1);
             PC_PHASE(2);
             PC_PHASE(3);
         }
-        if (t0 < kt_all) {                             // kt_all = 2 nst: two tiles left when nst is odd (a break inside the loop costs 16 accumulator copies per pass)
-            PC_PHASE(0);
-            PC_PHASE(1);
-        }
+        if (s0 < nst) PC_PHASE(0);
+        if (s0 + 1 < nst) PC_PHASE(1);
+        if (s0 + 2 < nst) PC_PHASE(2);
 #undef PC_PHASE
-#undef PC_MMA
-#undef PC_READ
+#undef PC_RAW_READ
+#undef PC_XADDR
         // ---- epilogue, part 1: accumulators -> LDS staging image (the rings are idle: every DMA has landed, every fragment is read).
         // accumulator j, value e of lane (r, hh): channel 32 wn + 8 (e >> 2) + 4 hh + (e & 3), row 64 wm + 32 j + r
+        PC_LGKM0();                                    // (the last phase's look-ahead reads)
         if constexpr (SPLIT) {
             constexpr int PITCH = PC_BN * 4 + 16;
 #pragma unroll
