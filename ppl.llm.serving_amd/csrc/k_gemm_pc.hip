@@ -11,13 +11,14 @@
 //     64-deep tile whose MFMAs take 256, profiles/r05_w4_pc_experiments.md);
 //   * waves 4..7 (producers) only issue LDS-DMA: the activation super-tile (two [128 rows][64 fp16] tiles, 8 one-KiB pieces per wave)
 //     into a 4-slot ring, the raw int4 weights (64 rows x 64 bytes, one piece per wave) and their group scales into 4-slot rings;
-//   * waves 0..3 (consumers, 2 (n) x 2 (m), each 32 (n) x 64 (m) on v_mfma_f32_32x32x16_f16) keep ONE register set of fragments that
-//     rolls: behind the two MFMAs of k-step ks of super-tile s, the activation fragments of k-step ks of super-tile s + 1 are read into
+//   * waves 0..3 (consumers on v_mfma_f32_32x32x16_f16: 2 (n) x 2 (k halves), each 32 (n) x 128 (m) x half of every super-tile's k, so that
+//     every weight is converted once per block; the halves are added through LDS at the end) keep ONE register set of fragments that
+//     rolls: behind the four MFMAs of k-step ks of super-tile s, the activation fragments of k-step ks of super-tile s + 1 are read into
 //     the registers those MFMAs just released, and the int4 weights of that k-step (8 nibbles per lane, read a super-tile earlier) are
 //     converted to fp16(q x scale) in registers (cvt_i4x8_f16) -- no fp16 weight image in LDS, no converter wave on the critical path
-//     (the first form of this kernel had both: its converter waves needed ~840 cycles per 64-deep tile, ibid.).  A lane half h multiplies
-//     k = 64 h + 8 ks .. + 8 of the super-tile in k-step ks (both operands use the same permutation of the contraction index), so that
-//     a lane's 32 weight bytes are contiguous and its activation chunk ks sits in the 64-deep tile h.
+//     (the first form of this kernel had both: its converter waves needed ~840 cycles per 64-deep tile, ibid.).  Lane half h of wave half kh multiplies
+//     k = 64 h + 32 kh + 8 ks .. + 8 of the super-tile in k-step ks (both operands use the same permutation of the contraction index), so that
+//     a lane's 16 weight bytes are one LDS read and its activation chunk 4 kh + ks sits in the 64-deep tile h.
 // LDS (148 KiB, one block per CU): X ring 4 x 32 KiB, 16-byte chunk q of row r of a tile at position q ^ ((r >> 1) & 7) (conflict-free
 // ds_read_b128 by 32 rows); raw ring 4 x 4 KiB [64 rows][64 B], chunk c of row r at c ^ ((r >> 2) & 3); scale ring 4 x 1 KiB (one
 // dword per producer lane).  Every global access of the producers is an LDS-DMA issued from inline asm (no VGPR destinations: nothing
@@ -165,40 +166,45 @@ __global__ __launch_bounds__(512) void gemm_w4_pc_kernel(const uint16_t* __restr
             if (j + 1 < nst) PC_VMCNT(20); else PC_VMCNT(0);   // last iteration: everything (the epilogue reuses the rings)
             __builtin_amdgcn_s_barrier();              // B_{j+1}
         }
+        __builtin_amdgcn_s_barrier();                  // (the consumers' barrier inside the exchange of their k halves)
     } else {
         // ------------------------------------------------------------------------------------------------------------------------
-        // consumer wave (wn, wm): 32 weight rows x 64 activation rows
+        // consumer wave (wn, kh): 32 weight rows x all 128 activation rows x HALF of every super-tile's k (lane half h, wave half kh:
+        // k = 64 h + 32 kh + 8 ks .. + 8 in k-step ks = 0..3).  Splitting the block's work by k instead of by m converts every weight ONCE
+        // per block: 76 conversion instructions per wave and super-tile beside 16 MFMAs -- a wave hides ~4 instructions per 32-cycle MFMA
+        // and pays ~5.3 cycles for each further one (profiles/probes/valu_beside_mfma_probe.hip), which is what held the m-split form
+        // (152 conversions per wave) at the old kernel's speed.  The two k halves are added through LDS at the end.
         // ------------------------------------------------------------------------------------------------------------------------
-        const int wn = wave & 1, wm = wave >> 1;
+        const int wn = wave & 1, kh = wave >> 1;
         const int r = lane & 31, hh = lane >> 5;
-        // activation fragment (ks, jm) of ring slot sl: tile hh of the super-tile, row 64 wm + 32 jm + r, chunk position ks ^ f(r).
+        // activation fragment (ks, jm) of ring slot sl: tile hh of the super-tile, row 32 jm + r, chunk position (4 kh + ks) ^ f(r).
         // Slots 2 and 3 lie beyond the 16-bit offset field of ds_read: a second base
-        const uint32_t xa = lds_addr(Xs) + hh * PC_XT + (64 * wm + r) * 128 + (((r >> 1) & 7) << 4);
-        uint32_t xlo[8], xhi[8];
+        const uint32_t xa = lds_addr(Xs) + hh * PC_XT + r * 128 + ((((r >> 1) & 7) ^ (4 * kh)) << 4);
+        uint32_t xlo[4], xhi[4];
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) { xlo[ks] = xa ^ (uint32_t)(ks << 4); xhi[ks] = xlo[ks] + 2 * PC_XB; }
+        for (int ks = 0; ks < 4; ++ks) { xlo[ks] = xa ^ (uint32_t)(ks << 4); xhi[ks] = xlo[ks] + 2 * PC_XB; }
         const int R = 32 * wn + r;
-        // raw weights: this lane's 32 bytes = chunks 2 hh, 2 hh + 1 of row R, stored at positions c ^ ((R >> 2) & 3)
-        const uint32_t ra0 = lds_addr(Raw) + R * 64 + (((2 * hh) ^ ((R >> 2) & 3)) << 4);
-        const uint32_t ra1 = lds_addr(Raw) + R * 64 + (((2 * hh + 1) ^ ((R >> 2) & 3)) << 4);
+        // raw weights: this lane's 16 bytes = chunk 2 hh + kh of row R, stored at position c ^ ((R >> 2) & 3)
+        const uint32_t ra = lds_addr(Raw) + R * 64 + (((2 * hh + kh) ^ ((R >> 2) & 3)) << 4);
         int nrow = n0 + R;
         if (nrow >= N) nrow = N - 1;
         const uint32_t nG = (uint32_t)nrow * (uint32_t)G;
         const uint32_t sa = lds_addr(Scl) + (R >> 4) * 256 + (R & 15) * 16;   // the dword its row's producer lanes fetched
 
-        f16v acc0, acc1;
+        f16v acc[4];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
-        uint4 xf[8][2];                                // activation fragments of the super-tile being multiplied (rolling)
-        h8 wf[8];                                      // its converted weight fragments (rolling)
-        uint4 rwa, rwb;                                // raw weights of the NEXT super-tile (words 0..3, 4..7 = its k-steps)
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        uint4 xf[4][4];                                // activation fragments of the super-tile being multiplied (rolling)
+        h8 wf[4];                                      // its converted weight fragments (rolling)
+        uint4 rw;                                      // raw weights of the NEXT super-tile (words = its k-steps)
         uint32_t scw;                                  // ... and the dword that holds its scale
 
 #define PC_XADDR(SL, KS, JM) (((SL) < 2 ? xlo[KS] : xhi[KS]) + (uint32_t)(((SL) & 1) * PC_XB + (JM) * 4096))
 #define PC_RAW_READ(SL)                                                                                                   \
     do {                                                                                                                  \
-        rwa = lds_ld16(ra0 + (SL) * PC_RAWB);                                                                             \
-        rwb = lds_ld16(ra1 + (SL) * PC_RAWB);                                                                             \
+        rw = lds_ld16(ra + (SL) * PC_RAWB);                                                                               \
         scw = lds_ld4(sa + (SL) * PC_SCB);                                                                                \
     } while (0)
         auto scale_of = [&](int g) {                   // the group scale in scw: element nG + g of the scale matrix
@@ -212,12 +218,12 @@ __global__ __launch_bounds__(512) void gemm_w4_pc_kernel(const uint16_t* __restr
         PC_RAW_READ(0);
         {
             const h2 sc2 = scale_of(g0);
-            const uint32_t wv[8] = {rwa.x, rwa.y, rwa.z, rwa.w, rwb.x, rwb.y, rwb.z, rwb.w};
+            const uint32_t wv[4] = {rw.x, rw.y, rw.z, rw.w};
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
+            for (int ks = 0; ks < 4; ++ks) {
                 wf[ks] = cvt_i4x8_f16(wv[ks], sc2);
-                xf[ks][0] = lds_ld16(PC_XADDR(0, ks, 0));
-                xf[ks][1] = lds_ld16(PC_XADDR(0, ks, 1));
+#pragma unroll
+                for (int jm = 0; jm < 4; ++jm) xf[ks][jm] = lds_ld16(PC_XADDR(0, ks, jm));
             }
         }
         PC_RAW_READ(1);
@@ -232,25 +238,21 @@ __global__ __launch_bounds__(512) void gemm_w4_pc_kernel(const uint16_t* __restr
         __builtin_amdgcn_s_barrier();                  /* B_{s+1} */                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                                \
         const h2 sc2 = scale_of(g0 + s0 + (P) + 1);                                                                       \
-        const uint32_t wv[8] = {rwa.x, rwa.y, rwa.z, rwa.w, rwb.x, rwb.y, rwb.z, rwb.w};                                  \
-        _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                                \
-            if (!(ABL & 1)) {                                                                                             \
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], __builtin_bit_cast(h8, xf[ks][0]), acc0, 0, 0, 0);  \
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], __builtin_bit_cast(h8, xf[ks][1]), acc1, 0, 0, 0);  \
-            }                                                                                                             \
-            if (!(ABL & 16)) {                                                                                            \
-                xf[ks][0] = lds_ld16(PC_XADDR(((P) + 1) & 3, ks, 0));                                                     \
-                xf[ks][1] = lds_ld16(PC_XADDR(((P) + 1) & 3, ks, 1));                                                     \
+        const uint32_t wv[4] = {rw.x, rw.y, rw.z, rw.w};                                                                  \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                                \
+            _Pragma("unroll") for (int jm = 0; jm < 4; ++jm) {                                                            \
+                if (!(ABL & 1)) acc[jm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], __builtin_bit_cast(h8, xf[ks][jm]), acc[jm], 0, 0, 0); \
+                if (!(ABL & 16)) xf[ks][jm] = lds_ld16(PC_XADDR(((P) + 1) & 3, ks, jm));                                  \
             }                                                                                                             \
             if (!(ABL & 2)) wf[ks] = cvt_i4x8_f16(wv[ks], sc2);                                                           \
         }                                                                                                                 \
         PC_RAW_READ(((P) + 2) & 3);                                                                                       \
-        _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                                \
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   /* two MFMAs */                                          \
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   /* the two fragment reads that refill their registers */ \
-            __builtin_amdgcn_sched_group_barrier(0x002, 20, 0);  /* the conversion of the same k-step of the next super-tile */ \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                                  \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   /* an MFMA */                                            \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   /* the fragment read that refills its register */        \
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   /* a quarter of a k-step's conversion for the next super-tile */ \
         }                                                                                                                 \
-        asm volatile("" : "+v"(acc0), "+v"(acc1));     /* the MFMAs stay in their phase (register-only: "memory" does not hold them) */ \
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));   /* the MFMAs stay in their phase (register-only: "memory" does not hold them) */ \
         __builtin_amdgcn_sched_barrier(0);                                                                                \
     } while (0)
         int s0 = 0;
@@ -266,42 +268,61 @@ __global__ __launch_bounds__(512) void gemm_w4_pc_kernel(const uint16_t* __restr
 #undef PC_PHASE
 #undef PC_RAW_READ
 #undef PC_XADDR
-        // ---- epilogue, part 1: accumulators -> LDS staging image (the rings are idle: every DMA has landed, every fragment is read).
-        // accumulator j, value e of lane (r, hh): channel 32 wn + 8 (e >> 2) + 4 hh + (e & 3), row 64 wm + 32 j + r
+        // ---- epilogue, part 1: the k halves are added through LDS (the rings are idle: every DMA has landed, every fragment is read),
+        // then accumulators -> LDS staging image.  accumulator j, value e of lane (r, hh): channel 32 wn + 8 (e >> 2) + 4 hh + (e & 3), row 32 j + r
         PC_LGKM0();                                    // (the last phase's look-ahead reads)
-        if constexpr (SPLIT) {
-            constexpr int PITCH = PC_BN * 4 + 16;
+        {
+            float4* const red = reinterpret_cast<float4*>(smem_pc + 64 * 1024);   // [wn][j][g][lane] float4: 32 KiB behind the staging image
+            if (kh == 1) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const f16v& a = j ? acc1 : acc0;
-                char* d = smem_pc + (64 * wm + 32 * j + r) * PITCH + (32 * wn + 4 * hh) * 4;
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4*>(d + g * 32) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+                    for (int g = 0; g < 4; ++g)
+                        red[((wn * 4 + j) * 4 + g) * 64 + lane] = make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
             }
-        } else if constexpr (EPI == EPI_F16) {
-            constexpr int PITCH = PC_BN * 2 + 16;
+            __builtin_amdgcn_s_barrier();              // (all eight waves: the producers meet it below)
+            if (kh == 0) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const f16v& a = j ? acc1 : acc0;
-                char* d = smem_pc + (64 * wm + 32 * j + r) * PITCH + (32 * wn + 4 * hh) * 2;
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const h4 o = {to_h(a[4 * g]), to_h(a[4 * g + 1]), to_h(a[4 * g + 2]), to_h(a[4 * g + 3])};
-                    *reinterpret_cast<uint2*>(d + g * 16) = __builtin_bit_cast(uint2, o);
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 o = red[((wn * 4 + j) * 4 + g) * 64 + lane];
+                        acc[j][4 * g] += o.x; acc[j][4 * g + 1] += o.y; acc[j][4 * g + 2] += o.z; acc[j][4 * g + 3] += o.w;
+                    }
+            }
+        }
+        if (kh == 0) {
+            if constexpr (SPLIT) {
+                constexpr int PITCH = PC_BN * 4 + 16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    char* d = smem_pc + (32 * j + r) * PITCH + (32 * wn + 4 * hh) * 4;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<float4*>(d + g * 32) = make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
                 }
-            }
-        } else {
-            constexpr int PITCH = PC_BN + 16;          // 32 outputs per row
+            } else if constexpr (EPI == EPI_F16) {
+                constexpr int PITCH = PC_BN * 2 + 16;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const f16v& a = j ? acc1 : acc0;
-                char* d = smem_pc + (64 * wm + 32 * j + r) * PITCH + (16 * wn + 2 * hh) * 2;
+                for (int j = 0; j < 4; ++j) {
+                    char* d = smem_pc + (32 * j + r) * PITCH + (32 * wn + 4 * hh) * 2;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float g0f = round_h(a[4 * g]), u0 = round_h(a[4 * g + 1]), g1f = round_h(a[4 * g + 2]), u1 = round_h(a[4 * g + 3]);
-                    const h2 o = {to_h(g0f / (1.0f + __expf(-g0f)) * u0), to_h(g1f / (1.0f + __expf(-g1f)) * u1)};
-                    *reinterpret_cast<uint32_t*>(d + g * 8) = __builtin_bit_cast(uint32_t, o);
+                    for (int g = 0; g < 4; ++g) {
+                        const h4 o = {to_h(acc[j][4 * g]), to_h(acc[j][4 * g + 1]), to_h(acc[j][4 * g + 2]), to_h(acc[j][4 * g + 3])};
+                        *reinterpret_cast<uint2*>(d + g * 16) = __builtin_bit_cast(uint2, o);
+                    }
+                }
+            } else {
+                constexpr int PITCH = PC_BN + 16;      // 32 outputs per row
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    char* d = smem_pc + (32 * j + r) * PITCH + (16 * wn + 2 * hh) * 2;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float g0f = round_h(acc[j][4 * g]), u0 = round_h(acc[j][4 * g + 1]), g1f = round_h(acc[j][4 * g + 2]), u1 = round_h(acc[j][4 * g + 3]);
+                        const h2 o = {to_h(g0f / (1.0f + __expf(-g0f)) * u0), to_h(g1f / (1.0f + __expf(-g1f)) * u1)};
+                        *reinterpret_cast<uint32_t*>(d + g * 8) = __builtin_bit_cast(uint32_t, o);
+                    }
                 }
             }
         }
