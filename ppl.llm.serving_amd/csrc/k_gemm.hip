@@ -701,27 +701,14 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         GEMV_DISPATCH(0) GEMV_DISPATCH(8) GEMV_DISPATCH(4)
 #undef GEMV_DISPATCH
     }
-    // W4A16 at a few hundred rows (config 4: the 70B / TP8 slice at batch 256): 128 x 64 tiles with converter waves beside MFMA waves
-    // (k_gemm_pc.hip, round 5).  No K slabs once the tiles fill most CUs; else as many as fill them, each at least four super-tiles deep.
-    static const int pc_mode = getenv("PPLHIP_GEMM_PC") ? atoi(getenv("PPLHIP_GEMM_PC")) : 1;   // 0: off (A/B runs)
-    if (pc_mode && wq_bit == 4 && M > 128 && M <= 512 && !force_generic && linear_w4_pc_supported(group, M, N, K, y, ldy, epi)) {
-        const int64_t tiles = (int64_t)((N + 63) / 64) * ((M + 127) / 128);
-        static const int forced_split = getenv("PPLHIP_GEMM_SPLITK") ? atoi(getenv("PPLHIP_GEMM_SPLITK")) : 0;
-        int splits = 1;
-        if (ws && tiles < 160) {
-            splits = (int)(256 / tiles);
-            if (splits > K / 128 / 4) splits = K / 128 / 4 > 0 ? K / 128 / 4 : 1;
-            if (splits > 8) splits = 8;                 // (SplitSlabs consumers sum at most 8)
-        }
-        if (forced_split > 0 && ws) splits = forced_split;
-        while (splits > 1 && (size_t)splits * M * N * sizeof(float) > ws_bytes) --splits;
-        const int G = K / 128, nst_per = (G + splits - 1) / splits;
-        splits = (G + nst_per - 1) / nst_per;
-        hipError_t e = launch_linear_w4_pc(s, x, w, scale, M, N, K, y, ldy, epi, splits, ws);
-        if (e != hipSuccess || splits == 1) return e;
-        if (defer && epi == EPI_F16 && N % 8 == 0 && splits <= 8) { *defer = SplitSlabs{ws, splits, nullptr, N, M}; return e; }
-        return launch_splitk_reduce(s, ws, splits, M, N, nullptr, y, ldy, epi);
-    }
+    // W4A16 at a few hundred rows (config 4: the 70B / TP8 slice at batch 256): 128 x 64 tiles, DMA waves beside MFMA waves whose fragment
+    // registers roll (k_gemm_pc.hip, round 5) -- for the shapes whose 128 x 64 tiles fill most CUs WITHOUT K slabs (wo / w13 / w2 of that
+    // slice: 256 / 224 / 256 blocks).  A shape that needs slabs anyway (wqkv: 40 tiles) stays on the ring kernel below: measured in the
+    // step, 12.70 -> 12.49 ms (profiles/r05_w4_pc_experiments.md).  PPLHIP_GEMM_PC=0: the ring kernel for everything (A/B runs)
+    static const int pc_mode = getenv("PPLHIP_GEMM_PC") ? atoi(getenv("PPLHIP_GEMM_PC")) : 1;
+    if (pc_mode && wq_bit == 4 && M > 128 && M <= 512 && !force_generic && (int64_t)((N + 63) / 64) * ((M + 127) / 128) >= 160 &&
+        linear_w4_pc_supported(group, M, N, K, y, ldy, epi))
+        return launch_linear_w4_pc(s, x, w, scale, M, N, K, y, ldy, epi);
     // W8A16 at 512 <= M < 4096 with N >= 8192 (wqkv / w13 of a decode step at batch ~1024): one 128 x 384 block per CU whose twelve
     // consumer waves share the activation tile (k_gemm_wide.hip) when its tiles fill the chip's rounds; PPLHIP_GEMM_WIDE=0: never
     static const int wide = getenv("PPLHIP_GEMM_WIDE") ? atoi(getenv("PPLHIP_GEMM_WIDE")) : 1;

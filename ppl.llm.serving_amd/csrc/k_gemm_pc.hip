@@ -6,7 +6,7 @@
 // 4 x on wo) and inside a wave each K tile was a serial wait -> barrier -> DMA issue -> int4 conversion -> fragment reads -> MFMA chain.
 // This kernel changes the decomposition and the schedule:
 //   * block tile 128 (m) x 64 (n): 224 / 256 / 256 blocks for w13 / wo / w2 of that layer -- one per CU, NO K slabs, outputs written once
-//     in fp16 through LDS (whole 128-byte rows); wqkv (40 tiles) keeps slabs that RoPE + KV write sums anyway;
+//     in fp16 through LDS (whole 128-byte rows); wqkv (40 tiles: slabs in any case) stays on the ring kernel, where it measured faster;
 //   * a K step is a SUPER-TILE of 128 = one quantisation group: one s_barrier per 128 deep (the barrier round trip was ~150 cycles of a
 //     64-deep tile whose MFMAs take 256, profiles/r05_w4_pc_experiments.md);
 //   * waves 4..7 (producers) only issue LDS-DMA: the activation super-tile (two [128 rows][64 fp16] tiles, 8 one-KiB pieces per wave)
@@ -79,12 +79,11 @@ __device__ __forceinline__ uint32_t lds_ld4(uint32_t a) {
 #endif
 #define PC_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-// EPI: EPI_F16 / EPI_SWIGLU.  SPLIT: K slabs (fp32 partial sums [split][M][N] at ws; the epilogue is applied by whoever sums them).
-template <int EPI, bool SPLIT>
+// EPI: EPI_F16 / EPI_SWIGLU
+template <int EPI>
 __global__ __launch_bounds__(512) void gemm_w4_pc_kernel(const uint16_t* __restrict__ x, const uint8_t* __restrict__ w,
                                                          const uint16_t* __restrict__ scale, int64_t M, int N, int K,
-                                                         void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles, int nst_per_split,
-                                                         float* __restrict__ ws, int abl_arg) {
+                                                         void* __restrict__ yv, int64_t ldy, int n_tiles, int m_tiles, int abl_arg) {
 #ifdef PC_ABLATE_BUILD   // diagnosis builds only (profiles/probes/w4_pc_ablate.sh; WRONG results): 1 no MFMAs, 2 no conversion, 4 no activation
     const int ABL = abl_arg;   // refills, 8 no raw-weight refills, 16 no fragment reads
 #else
@@ -103,9 +102,8 @@ __global__ __launch_bounds__(512) void gemm_w4_pc_kernel(const uint16_t* __restr
     const int n0 = nt * PC_BN;
     const int64_t m0 = (int64_t)mt * PC_BM;
     const int G = K >> 7;                              // super-tiles (= quantisation groups) along K
-    const int split_id = blockIdx.y;
-    const int g0 = split_id * nst_per_split;
-    const int nst = (g0 + nst_per_split < G) ? nst_per_split : G - g0;   // >= 1 (launcher)
+    constexpr int g0 = 0;
+    const int nst = G;                                 // >= 1 (launcher)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -133,7 +131,7 @@ __global__ __launch_bounds__(512) void gemm_w4_pc_kernel(const uint16_t* __restr
         const uint32_t xdst = __builtin_amdgcn_readfirstlane(lds_addr(Xs) + pw * 1024);
         const uint32_t rdst = __builtin_amdgcn_readfirstlane(lds_addr(Raw) + pw * 1024);
         const uint32_t sdst = __builtin_amdgcn_readfirstlane(lds_addr(Scl) + pw * 256);
-        const char* const xb = reinterpret_cast<const char*>(x) + (int64_t)g0 * 256;   // this split's first super-tile
+        const char* const xb = reinterpret_cast<const char*>(x);
 
         // DMA operations per super-tile and wave: raw weights (1), scales (1), activations (tile 0: 4 pieces, tile 1: 4 pieces).
         // Super-tiles past the end re-load the last one (into slots nobody reads any more): the wait counts stay static.
@@ -292,16 +290,7 @@ __global__ __launch_bounds__(512) void gemm_w4_pc_kernel(const uint16_t* __restr
             }
         }
         if (kh == 0) {
-            if constexpr (SPLIT) {
-                constexpr int PITCH = PC_BN * 4 + 16;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    char* d = smem_pc + (32 * j + r) * PITCH + (32 * wn + 4 * hh) * 4;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        *reinterpret_cast<float4*>(d + g * 32) = make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
-                }
-            } else if constexpr (EPI == EPI_F16) {
+            if constexpr (EPI == EPI_F16) {
                 constexpr int PITCH = PC_BN * 2 + 16;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -329,18 +318,7 @@ __global__ __launch_bounds__(512) void gemm_w4_pc_kernel(const uint16_t* __restr
     }
     // ---- epilogue, part 2 (all eight waves): whole rows of the staging image -> global memory, 16 bytes per lane
     __syncthreads();
-    if constexpr (SPLIT) {
-        constexpr int PITCH = PC_BN * 4 + 16, CPR = PC_BN / 4;
-        float* const slab = ws + (int64_t)split_id * M * N;
-#pragma unroll
-        for (int c = tid; c < PC_BM * CPR; c += 512) {
-            const int row = c / CPR, ch = c - row * CPR;
-            const int64_t m = m0 + row;
-            const int col = n0 + ch * 4;
-            if (m < M && col < N)                      // N % 4 == 0
-                *reinterpret_cast<float4*>(slab + m * N + col) = *reinterpret_cast<const float4*>(smem_pc + row * PITCH + ch * 16);
-        }
-    } else {
+    {
         constexpr int OUTW = EPI == EPI_SWIGLU ? PC_BN / 2 : PC_BN, PITCH = OUTW * 2 + 16, CPR = OUTW / 8;
         uint16_t* const y = reinterpret_cast<uint16_t*>(yv);
         const int nout = EPI == EPI_SWIGLU ? N / 2 : N, c0 = EPI == EPI_SWIGLU ? n0 / 2 : n0;
@@ -377,37 +355,28 @@ bool linear_w4_pc_supported(int group, int64_t M, int N, int K, const void* y, i
     return true;
 }
 
-// splits > 1: fp32 slabs [splits][M][N] at ws (the caller reduces them); nst_per_split super-tiles (128 k) per split
 hipError_t launch_linear_w4_pc(hipStream_t s, const uint16_t* x, const void* w, const uint16_t* scale, int64_t M, int N, int K, void* y,
-                               int64_t ldy, int epi, int splits, float* ws) {
+                               int64_t ldy, int epi) {
     const int n_tiles = (N + PC_BN - 1) / PC_BN, m_tiles = (int)((M + PC_BM - 1) / PC_BM);
-    const int G = K / 128;
-    if (splits < 1) splits = 1;
-    if (splits > G) splits = G;
-    const int nst_per = (G + splits - 1) / splits;
-    splits = (G + nst_per - 1) / nst_per;              // no empty split
     static bool attr_dev[64] = {false};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr_dev[dev & 63]) {
-        (void)hipFuncSetAttribute((const void*)gemm_w4_pc_kernel<EPI_F16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_w4_pc_kernel<EPI_SWIGLU, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_w4_pc_kernel<EPI_F16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_w4_pc_kernel<EPI_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_w4_pc_kernel<EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS);
         attr_dev[dev & 63] = true;
     }
-    dim3 grid((unsigned)((n_tiles + 7) / 8 * 8 * m_tiles), (unsigned)splits), block(512);
+    dim3 grid((unsigned)((n_tiles + 7) / 8 * 8 * m_tiles)), block(512);
     const uint8_t* wq = reinterpret_cast<const uint8_t*>(w);
 #ifdef PC_ABLATE_BUILD
     const int abl = getenv("PPLHIP_PC_ABL") ? atoi(getenv("PPLHIP_PC_ABL")) : 0;
 #else
     const int abl = 0;
 #endif
-    if (splits > 1)
-        hipLaunchKernelGGL((gemm_w4_pc_kernel<EPI_F16, true>), grid, block, PC_LDS, s, x, wq, scale, M, N, K, y, ldy, n_tiles, m_tiles, nst_per, ws, abl);
-    else if (epi == EPI_SWIGLU)
-        hipLaunchKernelGGL((gemm_w4_pc_kernel<EPI_SWIGLU, false>), grid, block, PC_LDS, s, x, wq, scale, M, N, K, y, ldy, n_tiles, m_tiles, nst_per, ws, abl);
+    if (epi == EPI_SWIGLU)
+        hipLaunchKernelGGL((gemm_w4_pc_kernel<EPI_SWIGLU>), grid, block, PC_LDS, s, x, wq, scale, M, N, K, y, ldy, n_tiles, m_tiles, abl);
     else
-        hipLaunchKernelGGL((gemm_w4_pc_kernel<EPI_F16, false>), grid, block, PC_LDS, s, x, wq, scale, M, N, K, y, ldy, n_tiles, m_tiles, nst_per, ws, abl);
+        hipLaunchKernelGGL((gemm_w4_pc_kernel<EPI_F16>), grid, block, PC_LDS, s, x, wq, scale, M, N, K, y, ldy, n_tiles, m_tiles, abl);
     return hipGetLastError();
 }
 

@@ -111,11 +111,10 @@ hipError_t launch_linear_w8_wide(hipStream_t s, const uint16_t* x, const int8_t*
 // the same block tile with a hand-allocated, hand-scheduled K loop (k_gemm_asm.hip + gen_gemm_asm.py); same contract
 hipError_t launch_linear_w8_asm(hipStream_t s, const uint16_t* x, const int8_t* w, const uint16_t* scale, int64_t M, int N, int K, void* y,
                                 int64_t ldy, int epi);
-// W4A16 (group 128) on 128 (m) x 64 (n) tiles with converter waves beside MFMA waves (k_gemm_pc.hip): a few hundred rows.  splits > 1:
-// fp32 slabs [splits][M][N] at ws, left to the caller (launch_splitk_reduce or a consuming kernel); epi 0 fp16 / 2 fused SwiGLU
+// W4A16 (group 128) on 128 (m) x 64 (n) tiles, no K slabs (k_gemm_pc.hip): a few hundred rows; epi 0 fp16 / 2 fused SwiGLU
 bool linear_w4_pc_supported(int group, int64_t M, int N, int K, const void* y, int64_t ldy, int epi);
 hipError_t launch_linear_w4_pc(hipStream_t s, const uint16_t* x, const void* w, const uint16_t* scale, int64_t M, int N, int K, void* y,
-                               int64_t ldy, int epi, int splits, float* ws);
+                               int64_t ldy, int epi);
 int linear_w8_wide_waves(int64_t M, int N);  // 12 when the 128 x 384 tiles fill rounds of 256 blocks well enough, else 0
 hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const uint16_t* scale, int wq_bit, int group,
                          int64_t M, int N, int K, void* y, int64_t ldy, bool out_fp32, float* ws = nullptr, size_t ws_bytes = 0,

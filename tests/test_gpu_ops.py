@@ -557,6 +557,23 @@ def test_linear_swiglu_fused(wq, M, inter, K):
     close_f16(y.cpu().numpy(), want, rel=rel, abs_=rel * mag * (0.25 if wq == 4 else 0.05) + 1e-5)
 
 
+@pytest.mark.parametrize("M,N,K", [(129, 5120, 128), (256, 5184, 384), (512, 2560, 640), (200, 10100, 256), (257, 6976, 1152),
+                                   (384, 3520, 2048)])
+def test_linear_w4_tiles_128x64_rolling_pipeline(M, N, K):
+    """gemm_w4_pc_kernel (k_gemm_pc.hip, round 5): W4A16 at 128 < M <= 512 when the 128 x 64 tiles fill the chip without K slabs -- one,
+    three and five super-tiles (the unrolled-by-four phase loop and each of its tails), ragged last weight tile (N % 64 != 0), ragged last
+    row tile, two to four row tiles.  Same oracle and tolerance as test_linear."""
+    assert ((N + 63) // 64) * ((M + 127) // 128) >= 160 and 128 < M <= 512   # the dispatcher's rule for this kernel (k_gemm.hip)
+    test_linear(4, M, N, K)
+
+
+@pytest.mark.parametrize("M,inter,K", [(256, 3584, 1024), (300, 2600, 384), (130, 5128, 128)])
+def test_linear_w4_tiles_128x64_swiglu(M, inter, K):
+    """... and its fused SwiGLU epilogue (w13 of config 4), incl. an output width that is not a multiple of 32."""
+    assert ((2 * inter + 63) // 64) * ((M + 127) // 128) >= 160
+    test_linear_swiglu_fused(4, M, inter, K)
+
+
 @pytest.mark.parametrize("wq", [0, 8, 4])
 @pytest.mark.parametrize("M", [1, 2, 3, 4])
 @pytest.mark.parametrize("N,K", [(4096, 4096), (12288, 4096), (4096, 11008), (1000, 384), (52, 128), (2000, 9600), (640, 24576)])
