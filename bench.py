@@ -200,19 +200,28 @@ def dry_run(args, P, dist, rank, world):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(0.001 * (rank + 1))
+    own = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    rank_ms = [own / max(args.steps, 1) * 1e3]
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
+        tmin = torch.tensor([own], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        rank_ms = [float(tmin.item()) / max(args.steps, 1) * 1e3, float(t.item()) / max(args.steps, 1) * 1e3]
         elapsed = float(t.item())
     if rank == 0:
         emit({"metric": "decode tokens/sec, LLaMA-7B int8 (W8A16), max-running-batch 1024", "value": 0.0,
                           "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4), "higher_is_better": True,
                           "scaling": "strong", "vs_baseline": None, "dry_run": True, "unique_id_agreed": agreed,
+                          "ms_per_step_ranks": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4)},
+                          "schedule": "none (dry run)",
+                          "collectives": {"mode": "none (dry run)", "selftest": "not run", "schedule": "none (dry run)", "rccl_communicator": False,
+                                          "two_stream_rows": [0, 0], "fallbacks": "", "allreduce_us": {"rows": 0, "bytes": 0, "chosen_path": None, "rccl": None}},
                           "config": {"workload": "dry run (no device work)", "parallelism": f"tp{world}"}})
     if dist is not None:
         dist.destroy_process_group()
@@ -346,6 +355,16 @@ def main():
         if all(h is not None for h in handles):
             ctx.comm_connect(handles)
     comm_mode = {0: "none", 1: "rccl", 2: "direct xGMI kernels (two-shot, all links)"}[ctx.comm_mode()]
+    # what this run's collectives are and cost (outside the timed region): mode, self-test verdict, schedule of the timed step, fallbacks
+    # taken, and a timed micro-loop of the step's own all-reduce message on the chosen path AND on RCCL -- so that a bad scaling curve can
+    # be read from the JSON line alone
+    collectives = ctx.comm_info(B)
+    if world > 1 or os.environ.get("PPLHIP_FORCE_COMM"):
+        try:
+            collectives["allreduce_us"] = {"rows": B, "bytes": B * desc.hidden_dim * 2, "chosen_path": ctx.comm_allreduce_us(B, 20, 0),
+                                           "rccl": ctx.comm_allreduce_us(B, 20, 1)}
+        except Exception as e:   # reporting only
+            collectives["allreduce_us"] = {"error": repr(e)}
     ctx.init_synthetic(0, 1234)
     kv_tokens = B * total_len if args.cache_mode == 0 else B * ((total_len + 15) // 16) * 16
     rag_kv = ragged_kv_lengths(B) if (args.ragged_steps > 0 and args.cache_mode == 0) else None
@@ -389,12 +408,18 @@ def main():
     t0 = time.perf_counter()
     for i in range(W, W + K):
         tok = step(i, tok)
+    ctx.sync(0)
+    own = time.perf_counter() - t0              # this rank's own time, before the closing barrier: the spread over ranks is reported
     barrier()
     elapsed = time.perf_counter() - t0
+    rank_ms = [own / max(K, 1) * 1e3]
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
+        tmin = torch.tensor([own], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        rank_ms = [float(tmin.item()) / max(K, 1) * 1e3, float(t.item()) / max(K, 1) * 1e3]
         elapsed = float(t.item())
 
     n_attn, ms_attn = ctx.profile_get(P.PROF_ATTN_DECODE)
@@ -498,6 +523,8 @@ def main():
             "value": round(B * K / elapsed, 2), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None,
+            "ms_per_step_ranks": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4)},
+            "schedule": collectives["schedule"], "collectives": collectives,
             "dtype": ("int8 activations x int8 weights (online_i8i8, W8A8), int32 accumulate" if args.act_quant == 8 else
                       "fp16 activations, int8 weights (W8A16), int8-g8 KV, fp32 accumulate"),
             "data": "synthetic (device-generated weights and KV history, random token ids)",

@@ -170,6 +170,24 @@ PPLHIP_API int pplhip_comm_connect(pplhip_ctx* ctx, const void* all_handles /* w
 /* collectives in use: 0 none (single rank), 1 RCCL, 2 direct kernels over peer-mapped memory */
 PPLHIP_API int pplhip_comm_mode(pplhip_ctx* ctx);
 
+/* What a multi-GPU run actually does, for the benchmark's report and for diagnosing a first run on real links (no counterpart in the
+ * reference, whose NCCL set-up either works or aborts: src/backends/cuda/resource_manager.cc:392-422).  Fallbacks are never silent: each
+ * one is printed on stderr when it is taken and kept in `notes` (direct collectives -> RCCL when the self-test fails on any rank;
+ * two-stream decode -> one stream when the second RCCL communicator cannot be created). */
+typedef struct pplhip_comm_info_t {
+    int32_t mode;           /* pplhip_comm_mode */
+    int32_t selftest;       /* direct collectives' start-up self-test: 0 not run, 1 passed on every rank, -1 failed */
+    int32_t schedule;       /* of a pure-decode step of `rows` rows: 0 collectives in-stream, 1 two half-batches on two streams, 2 two chunks
+                               with the collectives on the communication stream */
+    int32_t has_rccl;       /* an RCCL communicator exists */
+    int64_t dual_min_rows, dual_max_rows;   /* row window of the two-stream schedule (0, 0: off) */
+    char notes[512];
+} pplhip_comm_info_t;
+PPLHIP_API int pplhip_comm_info(pplhip_ctx* ctx, int64_t rows, pplhip_comm_info_t* out);
+/* average microseconds of one all-reduce of fp16 [rows, hidden_dim] (the step's own message) on `rank`'s stream over `iters` calls;
+ * path 0: the collectives in use, 1: RCCL.  *us = -1 when that path does not exist.  Collective: every rank calls it alike. */
+PPLHIP_API int pplhip_comm_allreduce_us(pplhip_ctx* ctx, int rank, int64_t rows, int32_t iters, int32_t path, float* us);
+
 PPLHIP_API const char* pplhip_last_error(pplhip_ctx* ctx, int rank);
 
 /* ================================================================================================

@@ -83,13 +83,13 @@ hipError_t launch_attn_decode(hipStream_t s, const uint16_t* qkv, const KvAddr& 
                               int64_t max_pages, int64_t nb, int H, int Hkv, int D, int64_t max_kv_len, int split,
                               int threads, float* workspace, uint16_t* out, hipEvent_t t0, hipEvent_t t1) {
     if (nb == 0) return hipSuccess;
-    static const int forced_tpb = getenv("PPLHIP_ATTN_TPB") ? atoi(getenv("PPLHIP_ATTN_TPB")) : 0;  // tuning only
+    static const int forced_tpb = tune_int("PPLHIP_ATTN_TPB", 0);  // tuning only
     if (forced_tpb) threads = forced_tpb;
     if (threads < 64 || threads > 64 * DEC_MAX_WAVES || threads % 64) return hipErrorInvalidValue;
     if (threads < D) threads = D;  // the final merge uses one thread per channel
     if (split < 1) split = 1;
     // grouped-query models: the MFMA kernel (k_attn_prefill.hip) reads each KV row once for the whole head group
-    static const bool no_gqa = getenv("PPLHIP_ATTN_NOGQA") != nullptr;
+    static const bool no_gqa = tune_set("PPLHIP_ATTN_NOGQA");
     if (attn_decode_gqa_supported(quant_bit, H, Hkv, D) && !no_gqa) {
         hipError_t e = launch_attn_decode_gqa(s, qkv, kv, quant_bit, seq_starts, start_pos, cache_indices, max_pages, nb, H,
                                               Hkv, D, split, workspace, out, t0, t1);

@@ -8,7 +8,7 @@
 //     oracle's own summation-order noise.  Now every MFMA operand is an exact hi + lo pair of fp16 numbers:
 //       K (V) : hi = fp16(q * s) (packed multiply), lo = fma(q, s, -hi) -- the error term of a floating-point product is itself
 //              exactly representable (TwoProduct), so hi + lo == q * s exactly, for 1.5 packed VALU ops per element
-//              (V: only with GQ_V_EXACT = 1, see below; by default V is the hi term alone);
+//              (V: with GQ_V_EXACT = 1, the default; see below);
 //       P    : hi = fp16(p), lo = fp16(p - hi) (22 significant bits);
 //     S = Q.(Khi + Klo)  (two MFMAs per k-step), O += (Phi + Plo).(Vhi + Vlo).  The P.V MFMA contracts over 32 k-slots but
 //     a wave's sub-tile has only 16 keys, so the lo terms ride in the k-slots that used to be zero: A = (Phi | Plo),
@@ -37,12 +37,14 @@ constexpr int GQ_WAVES = GQ_THREADS / 64;
 #ifndef GQ_NBUF
 #define GQ_NBUF 2   // measured 2 / 3 / 4: 4.46 / 4.07 / 4.16 TB/s at B 256, kv 2048 (the kernel is issue-bound, not latency-bound): 16-key sub-tiles in flight per wave (register buffers, statically rotated)
 #endif
-// GQ_V_EXACT 0 (round 4, default): V = int8 x scale rounded to fp16 ONCE (round to nearest, as both prefill kernels take it) -- one LDS image,
-// one MFMA per channel block, 16 packed VALU ops less per sub-tile: config 4 (B 256, kv 2048, 8 : 1) 4.48-4.62 -> 4.84 TB/s = 60.5 % of 8 TB/s;
-// against the oracle 6.4e-5 -> 2.6e-4 of max|out| at that shape (tolerance 1.5e-3; K, whose rounding the exponent amplifies -- the round-2
-// kernel's 4e-3 -- and P stay exact hi + lo pairs).  1: V as an exact hi + lo pair as well (round 3).
+// GQ_V_EXACT 1 (default again in round 5): V as an exact hi + lo pair like K and P.  Round 4 took V as int8 x scale rounded to fp16 ONCE
+// (one LDS image, one MFMA per channel block, 16 packed VALU ops less per sub-tile: config 4 4.48-4.62 -> 4.84 TB/s) for 6.4e-5 -> 2.6e-4
+// of max|out| at the operator -- and that term turned out to be what put the 70B / TP8 W4A16 model case at 1.35e-3 of max|logit| = 1.9 x
+// the oracle's own noise floor and 0.90 of its cap (profiles/r05_w4_gqa_margin.log: 0.57e-3 = 0.8 x the floor with V exact, same
+// library otherwise), which in turn kept the faster RMSNorm form switched off.  Precision first: exact V, and the RMSNorm form pays the
+// time back (config 4 per rank: +0.25 ms and -0.25 ms).  0: the rounded form (build switch).
 #ifndef GQ_V_EXACT
-#define GQ_V_EXACT 0
+#define GQ_V_EXACT 1
 #endif
 constexpr int GQ_VSUB = 272;  // halfs per [16 keys][16 channels] V sub-tile in LDS: 256 + 16 of skew (bank spread of the writes)
 

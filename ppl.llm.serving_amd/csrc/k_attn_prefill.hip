@@ -397,12 +397,12 @@ hipError_t launch_attn_prefill(hipStream_t s, const uint16_t* qkv, const KvAddr&
                                uint16_t* out, int64_t max_kv_len, float* ws, size_t ws_bytes, int64_t row0, int64_t nrows) {
     if (B <= b0 || max_seq_len <= 0) return hipSuccess;
     // head_dim 128: the 32-row kernel of k_attn_prefill32.hip (PPLHIP_PREFILL32=0 selects this file's 16-row kernel for A/B runs)
-    static const int p32 = getenv("PPLHIP_PREFILL32") ? atoi(getenv("PPLHIP_PREFILL32")) : 1;
+    static const int p32 = tune_int("PPLHIP_PREFILL32", 1);
     if (p32 && D == 128 && (quant_bit == 0 || quant_bit == 8)) return launch_attn_prefill32(s, qkv, kv, quant_bit, seq_starts, start_pos, cache_indices, max_pages, b0, B, H, Hkv, D, max_seq_len, out, max_kv_len, ws, ws_bytes, row0, nrows);
     // RG = 2 (256 query rows per block, Q fragments in LDS) halves the staging per MFMA but spills registers and measured
     // slower than RG = 1 once the softmax was trimmed (8192-token prompt: 1.86 ms vs 1.43 ms per layer); PPLHIP_PREFILL_RG=2 keeps
     // it reachable for experiments
-    static const int forced_rg = getenv("PPLHIP_PREFILL_RG") ? atoi(getenv("PPLHIP_PREFILL_RG")) : 0;
+    static const int forced_rg = tune_int("PPLHIP_PREFILL_RG", 0);
     const int rg = forced_rg == 2 ? 2 : 1;
     const int bm = PF_BM * rg;
     const int nqb = (int)((max_seq_len + bm - 1) / bm), nreq = (int)(B - b0);

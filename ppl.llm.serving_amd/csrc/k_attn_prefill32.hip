@@ -412,7 +412,7 @@ hipError_t launch_attn_prefill32(hipStream_t s, const uint16_t* qkv, const KvAdd
     }
     // 8 waves (256 query rows per block: each staged K / V tile serves twice the rows) once the sequences are long enough: 8192 new
     // tokens 1002 vs 1043 us, 2048 over a 6144-token cache 481 vs 538 us, but 16 x 512 tokens 105 vs 101 us
-    static const int nw_env = getenv("PPLHIP_P32_NW") ? atoi(getenv("PPLHIP_P32_NW")) : 0;
+    static const int nw_env = tune_int("PPLHIP_P32_NW", 0);
     const int nw = nw_env ? nw_env : (max_seq_len >= 1024 ? 8 : 4);
     const int bm = nw * 32;
     const int nqb = (int)((max_seq_len + bm - 1) / bm), nreq = (int)(B - b0);
@@ -420,7 +420,7 @@ hipError_t launch_attn_prefill32(hipStream_t s, const uint16_t* qkv, const KvAdd
 #define P3_LAUNCH(QB, MD, NW_) hipLaunchKernelGGL((attn_prefill32_kernel<QB, MD, NW_>), grid, dim3(NW_ * 64), 0, s, qkv, kv, seq_starts, start_pos, \
                                                   cache_indices, max_pages, b0, H, Hkv, nreq, nqb, out, nullptr, 0)
 #ifdef P3_ABLATE_BUILD  // diagnosis build (profiles/r03_prefill_attention_ablation.md): wrong results, same instruction stream otherwise
-    static const int abl = getenv("PPLHIP_P32_ABLATE") ? atoi(getenv("PPLHIP_P32_ABLATE")) : 0;
+    static const int abl = tune_int("PPLHIP_P32_ABLATE", 0);
 #define P3_ABL(A) if (abl == A && nw == 8) { hipLaunchKernelGGL((attn_prefill32_kernel<8, 0, 8, A>), grid, dim3(512), 0, s, qkv, kv, seq_starts, start_pos, cache_indices, max_pages, b0, H, Hkv, nreq, nqb, out, nullptr, 0); return hipGetLastError(); }
     P3_ABL(1) P3_ABL(2) P3_ABL(3) P3_ABL(7)
 #undef P3_ABL

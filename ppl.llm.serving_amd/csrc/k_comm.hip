@@ -231,7 +231,7 @@ int grid_for(int64_t granules_per_rank) {
     // blocks of several ranks emulated on ONE device (tests) never fill it
     int64_t b = (granules_per_rank + 512 * 8 - 1) / (512 * 8);
     if (b < 1) b = 1;
-    static const int cap = getenv("PPLHIP_P2P_BLOCKS") ? atoi(getenv("PPLHIP_P2P_BLOCKS")) : 32;
+    static const int cap = tune_int("PPLHIP_P2P_BLOCKS", 32);
     const int c = cap < 1 ? 1 : (cap > P2P_MAX_BLOCKS ? P2P_MAX_BLOCKS : cap);
     return (int)(b > c ? c : b);
 }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace pplhip {
 
@@ -12,6 +13,28 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int WAVE = 64;
+
+// Tuning switches of the launch heuristics (tile shapes, ring depths, split-K counts ...): the PRODUCT reads none of them -- the values the
+// measurements of profiles/ settled on are compiled in.  A tuning build (make TUNING=1: -DPPLHIP_TUNING_BUILD) reads them from the
+// environment, which is what the sweep scripts under profiles/probes/ use.  (Switches the product does read -- collectives, schedules,
+// the A/B switches of recent changes -- are listed in INTEGRATION.md with their defaults.)
+inline int tune_int(const char* name, int dflt) {
+#ifdef PPLHIP_TUNING_BUILD
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+inline bool tune_set(const char* name) {
+#ifdef PPLHIP_TUNING_BUILD
+    return getenv(name) != nullptr;
+#else
+    (void)name;
+    return false;
+#endif
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -140,10 +140,11 @@ hipError_t launch_rmsnorm(hipStream_t s, const uint16_t* x, const uint16_t* skip
                        chunks, hidden, gather_seq_starts, (uint4*)out, (uint4*)residual_out, qout, sx, sl)
     // few rows of a wide model (decode steps of 5..512 rows at hidden >= 4096): one chunk per thread on 512 / 1024 threads -- every load of
     // the row is in flight at once.  (Up to 4 rows stay on the 256-thread form: the fused GEMV norm of k_gemv.hip restates ITS summation order.)
-    // OPT-IN (PPLHIP_RMSNORM_WIDE_MAX_ROWS=512): -1.9 % on config 4's per-rank step and -0.4..-1.7 % on 7B steps of 8-512 rows, but the other
-    // summation order of the sum of squares moves the 70B / TP8 W4A16 parity case (tests/test_gpu_tp.py, an ill-conditioned synthetic geometry:
-    // profiles/r04_late_experiments.md sections 4 and 7) from < 1.5e-3 to 1.66e-3 of max|logit| -- over its fixed cap, so it is not the default
-    static const int wide_rows = getenv("PPLHIP_RMSNORM_WIDE_MAX_ROWS") ? atoi(getenv("PPLHIP_RMSNORM_WIDE_MAX_ROWS")) : 0;
+    // -1.9 % on config 4's per-rank step and -0.4..-1.7 % on 7B steps of 8-512 rows (profiles/r04_rmsnorm_wide_ab.log).  Round 4 kept it
+    // opt-in: its summation order moved the 70B / TP8 W4A16 parity case over its fixed cap -- a case that the grouped-query decode kernel's
+    // rounded V had already brought to 0.90 of that cap; with V exact again (k_attn_decode_gqa.hip, round 5) the case sits at 0.89e-3 = 1.27 x
+    // the oracle's noise floor WITH this form (profiles/r05_w4_gqa_margin.log).  PPLHIP_RMSNORM_WIDE_MAX_ROWS=0: the 256-thread form (A/B runs)
+    static const int wide_rows = getenv("PPLHIP_RMSNORM_WIDE_MAX_ROWS") ? atoi(getenv("PPLHIP_RMSNORM_WIDE_MAX_ROWS")) : 512;
     if (rows > 4 && rows <= wide_rows && chunks >= 512 && chunks <= 1024 && chunks % 64 == 0) {
         if (chunks <= 512) hipLaunchKernelGGL((rmsnorm_kernel<1, 512>), g, dim3(512), 0, s, (const uint4*)x, (const uint4*)skip, (const uint4*)w, eps,
                                               chunks, hidden, gather_seq_starts, (uint4*)out, (uint4*)residual_out, qout, sx, sl);

@@ -614,7 +614,7 @@ static hipError_t launch_gemv(hipStream_t s, const uint16_t* x, const void* w, c
                               int N, int K, void* y, int64_t ldy) {
     dim3 grid((unsigned)((N + 15) / 16));
     const int mt = (int)((M + 15) / 16);
-    static const int forced_nw = getenv("PPLHIP_GEMV_WAVES") ? atoi(getenv("PPLHIP_GEMV_WAVES")) : 0;
+    static const int forced_nw = tune_int("PPLHIP_GEMV_WAVES", 0);
     // up to 1024 row tiles -> 8 K slices per tile so that every CU has enough waves streaming (profiles/gemm_microbench.py)
     const int nw = forced_nw ? forced_nw : ((N + 15) / 16 <= 1024 ? 8 : 4);
 #define GEMV_CASE(MT)                                                                                                    \
@@ -673,7 +673,7 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
     // request) would add a ninth / seventeenth 128-row tile to every column block -- a whole extra round of tiles for a few rows (7B layer
     // GEMMs at M = 1040: 555 us against 414 us at M = 1024).  The rows up to the multiple go through the shapes that fit, the rest as a
     // second, small launch.
-    static const int msplit = getenv("PPLHIP_GEMM_MSPLIT") ? atoi(getenv("PPLHIP_GEMM_MSPLIT")) : 256;  // largest rest that is split off (0: never); measured: rest 16 / 76 / 128 / 256 -13 / -10 / -11 / -5 %, 384 equal
+    static const int msplit = tune_int("PPLHIP_GEMM_MSPLIT", 256);  // largest rest that is split off (0: never); measured: rest 16 / 76 / 128 / 256 -13 / -10 / -11 / -5 %, 384 equal
     if (msplit && M > 1024 && M < 3584 && (M & 1023) != 0 && (M & 1023) <= msplit) {
         const int64_t m_main = M & ~(int64_t)1023, m_rest = M - m_main;
         const size_t yelt = out_fp32 ? 4 : 2;
@@ -682,16 +682,16 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         return launch_linear(s, x + m_main * K, w, scale, wq_bit, group, m_rest, N, K, (char*)y + (size_t)m_main * ldy * yelt, ldy, out_fp32, ws,
                              ws_bytes, swiglu);
     }
-    static const bool no_skinny = getenv("PPLHIP_GEMM_NOSKINNY") != nullptr, force_generic = getenv("PPLHIP_GEMM_GENERIC") != nullptr;
+    static const bool no_skinny = tune_set("PPLHIP_GEMM_NOSKINNY"), force_generic = tune_set("PPLHIP_GEMM_GENERIC");
     // the skinny kernel up to 3 rows; from 4 rows the half-height tile kernel (64 activation rows, split-K) is faster: 7B decode step at batch
     // 4 / 8 / 12 / 16 3.64 / 3.90 / 4.40 / 4.74 -> 3.56 / 3.73 / 3.81 / 4.18 ms (profiles/small_batch_latency.py); PPLHIP_GEMV_MAX_M overrides
-    static const int gemv_max_m = getenv("PPLHIP_GEMV_MAX_M") ? atoi(getenv("PPLHIP_GEMV_MAX_M")) : 3;
+    static const int gemv_max_m = tune_int("PPLHIP_GEMV_MAX_M", 3);
     // up to 4 rows (PPLHIP_GEMV_STREAM_MAX_M): the streaming GEMV of k_gemv.hip -- whole 1-KiB row pieces per wave-load, no matrix unit
     if (M <= gemv_stream_max_m(wq_bit, group, N, K) && !no_skinny && !force_generic)
         return launch_gemv_stream(s, x, w, scale, wq_bit, group, M, N, K, y, ldy, epi);
     // (without a split-K workspace the half-height tiles would run as N / 128 unsplit blocks: the skinny kernel keeps its 16 rows there)
     // (int8 weights with K % 128 == 0: from 3 rows the half-height tiles with 16-row activation sub-tiles are faster than either GEMV)
-    const int skinny_max = wq_bit == 8 && K % (G_BK * 2) == 0 && gemv_max_m > 2 && !getenv("PPLHIP_GEMV_MAX_M") ? 2 : gemv_max_m;
+    const int skinny_max = wq_bit == 8 && K % (G_BK * 2) == 0 && gemv_max_m > 2 && !tune_set("PPLHIP_GEMV_MAX_M") ? 2 : gemv_max_m;
     if (M <= (ws && ws_bytes ? skinny_max : 16) && M <= 16 && !no_skinny) {
 #define GEMV_DISPATCH(WQ)                                                                                      \
     if (wq_bit == WQ)                                                                                          \
@@ -711,7 +711,7 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         return launch_linear_w4_pc(s, x, w, scale, M, N, K, y, ldy, epi);
     // W8A16 at 512 <= M < 4096 with N >= 8192 (wqkv / w13 of a decode step at batch ~1024): one 128 x 384 block per CU whose twelve
     // consumer waves share the activation tile (k_gemm_wide.hip) when its tiles fill the chip's rounds; PPLHIP_GEMM_WIDE=0: never
-    static const int wide = getenv("PPLHIP_GEMM_WIDE") ? atoi(getenv("PPLHIP_GEMM_WIDE")) : 1;
+    static const int wide = tune_int("PPLHIP_GEMM_WIDE", 1);
     if (wide && wq_bit == 8 && K % G_BK == 0 && M >= 512 && (M < 4096 || wide == 2) && N >= 8192) {
         const int nc = wide == 2 ? 12 : linear_w8_wide_waves(M, N);  // (2: experiments -- every eligible shape, any M)
         // PPLHIP_GEMM_ASM=1: the same block tile on the hand-scheduled K loop of k_gemm_asm.hip (round 4).  Equal speed on random
@@ -724,14 +724,14 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
     const int m_tiles = (int)((M + G_BM - 1) / G_BM);
     const int n_tiles_pad = (n_tiles + 7) / 8 * 8;
     dim3 grid((unsigned)(n_tiles_pad * m_tiles)), block(256);
-    static const int min_m256 = getenv("PPLHIP_GEMM_256_MIN_M") ? atoi(getenv("PPLHIP_GEMM_256_MIN_M")) : 3584;  // measured (7B layer): M = 3584 1435 vs 1501 us, 3072 1277 vs 1264, 2560 equal, 2048 941 vs 851
+    static const int min_m256 = tune_int("PPLHIP_GEMM_256_MIN_M", 3584);  // measured (7B layer): M = 3584 1435 vs 1501 us, 3072 1277 vs 1264, 2560 equal, 2048 941 vs 851
     if (wq_bit == 8 && K % G_BK == 0 && M >= min_m256 && N >= 1024 && !force_generic) {
         const int nt2 = (N + H_BN - 1) / H_BN, mt2 = (int)((M + H_BM - 1) / H_BM);
         const size_t lds = (size_t)H_ST * (H_BM * G_BK * 2 + H_BN * G_BK);
         // super-tile shape: gm = the largest divisor of mt2 <= 4 (X tiles carry twice the bytes of W tiles), gn = up to 8 weight tiles
         // of the XCD's share; the share is padded to whole super-tiles (the extra blocks return at once)
-        static const int forced_gm = getenv("PPLHIP_GEMM256_GM") ? atoi(getenv("PPLHIP_GEMM256_GM")) : 0;
-        static const int forced_gn = getenv("PPLHIP_GEMM256_GN") ? atoi(getenv("PPLHIP_GEMM256_GN")) : 0;
+        static const int forced_gm = tune_int("PPLHIP_GEMM256_GM", 0);
+        static const int forced_gn = tune_int("PPLHIP_GEMM256_GN", 0);
         const int nl = (nt2 + 7) / 8;  // weight tiles per XCD
         int gm = 4;
         if (forced_gm > 0) gm = forced_gm;
@@ -753,7 +753,7 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
             (void)hipFuncSetAttribute((const void*)gemm_w8_dma256_kernel<EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }
-        static const int no_stage = getenv("PPLHIP_GEMM_DIRECT_EPILOGUE") ? 1 : 0;  // A/B runs
+        static const int no_stage = tune_set("PPLHIP_GEMM_DIRECT_EPILOGUE") ? 1 : 0;  // A/B runs
         const int staged = !no_stage && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0 && (epi != EPI_SWIGLU || N % 16 == 0) ? 1 : 0;
 #define L256(E) hipLaunchKernelGGL((gemm_w8_dma256_kernel<E>), g256, dim3(512), lds, s, x, (const int8_t*)w, scale, M, N, K, y, ldy, nt2, mt2, gn, gm, staged)
         if (epi == EPI_F32) L256(EPI_F32); else if (epi == EPI_F16) L256(EPI_F16); else L256(EPI_SWIGLU);
@@ -767,17 +767,17 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
     // fragment converted once for 16 MFMAs instead of 8 -- is SLOWER on the 70B / TP8 shapes: w13 49.1 -> 53.4 us, w2 31.5 -> 38.9 us at
     // M = 256; 236 VGPRs and 88 KiB of LDS leave one wave per SIMD.  profiles/r04_w4_m256_sweep.log)
     if ((wq_bit == 8 || wq_bit == 0 || w4_fast) && K % G_BK == 0 && !force_generic) {
-        static const int forced = getenv("PPLHIP_GEMM_MAP") ? atoi(getenv("PPLHIP_GEMM_MAP")) : -1;
+        static const int forced = tune_int("PPLHIP_GEMM_MAP", -1);
         // measured (profiles/gemm_microbench.py, M = 1024): weight tiles per XCD (mode 0) beats activation slices per XCD
         // (mode 1) by 2-4 % on every layer shape
         int map_mode = (forced == 1 && m_tiles % 8 == 0) ? 1 : 0;
         dim3 g2 = map_mode == 1 ? dim3((unsigned)(n_tiles * m_tiles)) : grid;
-        static const bool force_super = getenv("PPLHIP_GEMM128_GM") != nullptr;  // experiments at M <= 1024
+        static const bool force_super = tune_set("PPLHIP_GEMM128_GM");  // experiments at M <= 1024
         if (map_mode == 0 && (m_tiles > 8 || force_super)) {
             // more than 8 activation tiles (M > 1024): walk the XCD's weight tiles in super-tiles of 12 (n) x 8 (m) -- at M = 1024 the
             // plain order already is that shape; at M = 8192 it degenerates to 1.5 weight tiles x 64 activation tiles in flight per XCD
-            static const int forced_gm = getenv("PPLHIP_GEMM128_GM") ? atoi(getenv("PPLHIP_GEMM128_GM")) : 0;
-            static const int forced_gn = getenv("PPLHIP_GEMM128_GN") ? atoi(getenv("PPLHIP_GEMM128_GN")) : 0;
+            static const int forced_gm = tune_int("PPLHIP_GEMM128_GM", 0);
+            static const int forced_gn = tune_int("PPLHIP_GEMM128_GN", 0);
             int gm = forced_gm > 0 ? forced_gm : 8;
             while (gm > 1 && m_tiles % gm) --gm;
             const int nl = n_tiles_pad / 8;
@@ -788,9 +788,9 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
                 g2 = dim3((unsigned)(8 * ((nl + gn - 1) / gn * gn) * m_tiles));
             }
         }
-        static const int ablate = getenv("PPLHIP_GEMM_ABLATE") ? atoi(getenv("PPLHIP_GEMM_ABLATE")) : 0;  // diagnosis only: wrong results
+        static const int ablate = tune_int("PPLHIP_GEMM_ABLATE", 0);  // diagnosis only: wrong results
         map_mode |= ablate << 8;
-        static const int forced_st = getenv("PPLHIP_GEMM_STAGES") ? atoi(getenv("PPLHIP_GEMM_STAGES")) : 0;
+        static const int forced_st = tune_int("PPLHIP_GEMM_STAGES", 0);
         // few blocks per CU -> deeper ring (latency is hidden inside the block); many -> more blocks per CU
         int stages = (int64_t)n_tiles * m_tiles <= 256 ? 4 : 2;  // measured: profiles/gemm_microbench.py
         if (forced_st >= 2 && forced_st <= 4) stages = forced_st;
@@ -798,13 +798,13 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         // split-K for small M: too few output tiles to pull HBM bandwidth (weights must stream at full rate)
         const int kt_all = K / G_BK;
         int splits = 1;
-        static const int forced_split = getenv("PPLHIP_GEMM_SPLITK") ? atoi(getenv("PPLHIP_GEMM_SPLITK")) : 0;
+        static const int forced_split = tune_int("PPLHIP_GEMM_SPLITK", 0);
         const int64_t tiles = (int64_t)n_tiles * m_tiles;
         // (also at larger M when a tensor-parallel slice leaves fewer output tiles than CUs)
         if (ws && ((M <= 256 && tiles < 512) || tiles < 200 || forced_split > 0)) {
             // enough blocks to fill the chip, but every split writes an fp32 slab of the whole output: keep >= min_kt K
             // tiles per split (measured at M = 64 / 256 on the 70B/TP8 shapes and M = 1024 on 7B/TP8 slices)
-            static const int env_minkt = getenv("PPLHIP_GEMM_MINKT") ? atoi(getenv("PPLHIP_GEMM_MINKT")) : 0;
+            static const int env_minkt = tune_int("PPLHIP_GEMM_MINKT", 0);
             const int target = M <= 64 ? 768 : 512;
             splits = (int)((target + tiles - 1) / tiles);
             const int cap = (M <= 64 || tiles <= 32) ? 8 : 4;  // (M = 128..256 sweeps: more than 4 slabs never paid)
@@ -823,7 +823,7 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         // W8 7B at M = 256 wo 21.3 -> 19.8 us, w2 38.8 -> 33.4; 13B / TP2 at M = 512 wo 28.0 -> 24.3, w2 56.8 -> 52.1; fp16 70B / TP8 w2 30.0 ->
         // 26.0; W4 70B / TP8 w2 31.1 -> 30.1 (profiles/r04_splitk_stages_sweep.log).  Until the last session of round 4 this line forced two
         // stages on EVERY split launch and overrode PPLHIP_GEMM_STAGES, so the earlier stage sweeps never ran 3 / 4 stages on split shapes.
-        static const int split_deep = getenv("PPLHIP_GEMM_SPLIT_DEEP") ? atoi(getenv("PPLHIP_GEMM_SPLIT_DEEP")) : 1;   // 0: always two stages
+        static const int split_deep = tune_int("PPLHIP_GEMM_SPLIT_DEEP", 1);   // 0: always two stages
         // (W4 half-height tiles at M <= 64 are the exception: w2 of the 70B / TP8 slice 19.4 -> 21.0 us with the deep ring.)  In the steps:
         // 7B / TP8 slice at 1024 rows 7.97 -> 7.69 ms, config 4 per rank 13.68 -> 13.54, 7B TP 1 at batch 160-512 -0.3..-1.9 % (r04_split_deep_ab.log)
         if (splits > 1 && !(forced_st >= 2 && forced_st <= 4))
@@ -832,27 +832,27 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         // at most one block per CU (<= 256 blocks): 8 waves, 4 of them producers that only issue the ring's LDS-DMA (two waves
         // per SIMD from the one block, the DMA issue runs beside the MFMA stream: wo 59 -> 46 us, w2 120 -> 95 us at
         // M = 1024); more blocks: 4 waves of 32(n) x 128(m), two blocks per CU (the specialised form is not faster there)
-        static const int forced_wl = getenv("PPLHIP_GEMM_WL") ? atoi(getenv("PPLHIP_GEMM_WL")) : 0;
+        static const int forced_wl = tune_int("PPLHIP_GEMM_WL", 0);
         int wl = (forced_wl == 1 || forced_wl == 5) ? forced_wl : (tiles * splits <= 256 ? 5 : 1);
         // 16 < M <= 64: half-height tiles (64 activation rows), 4-wave blocks
-        static const int forced_half = getenv("PPLHIP_GEMM_HALF") ? atoi(getenv("PPLHIP_GEMM_HALF")) : -1;
+        static const int forced_half = tune_int("PPLHIP_GEMM_HALF", -1);
         const bool half = forced_half >= 0 ? (forced_half == 1 && M <= 64) : M <= 64;  // 7B layer GEMMs at M = 64: 102 -> 84 us, M = 32: 90 -> 74 us
         if (half) wl = 1;
         // W8, one block per CU: eight consumer waves, each group multiplying one of the two k-steps of a tile (w2 at M = 1024: 100 -> 96 us)
         if ((forced_wl == 6 || (forced_wl == 0 && wl == 5)) && wq_bit == 8 && stages >= 3 && splits == 1) wl = 6;
         // W8, half-height tiles: the 128-deep K tile (whole 128-byte lines of every weight row per LDS-DMA piece; gemm_w8_half128_kernel),
         // activation sub-tile 16 / 32 / 64 rows; three stages when two blocks of them fit a CU (BM <= 32) or the grid is one block per CU
-        static const int half128 = getenv("PPLHIP_GEMM_HALF128") ? atoi(getenv("PPLHIP_GEMM_HALF128")) : 1;  // 0: off; 2: always 64-row sub-tiles
+        static const int half128 = tune_int("PPLHIP_GEMM_HALF128", 1);  // 0: off; 2: always 64-row sub-tiles
         // ... and 64 < M <= 128 with 80- .. 128-row sub-tiles (steps of 16 rows; three stages, one block per CU) for the shapes that need split-K
         // anyway (7B at M = 128, HBM-cold: wqkv 33.1 -> 29.3 us, wo 21.2 -> 18.9, w2 27.9 -> 26.3; w13 -- 172 tiles, no split -- stays on the
         // 128 x 128 ring kernel with its eight consumer waves above 80 rows: 34.7 against 42.0 us at 128).  Decode step at batch 72 / 96 / 128
         // 6.20 / 6.85 / 7.92 -> 5.70 / 6.53 / 7.76 ms.  PPLHIP_GEMM_HALF128_MAX_M=64: off
-        static const int half128_max_m = getenv("PPLHIP_GEMM_HALF128_MAX_M") ? atoi(getenv("PPLHIP_GEMM_HALF128_MAX_M")) : 128;
+        static const int half128_max_m = tune_int("PPLHIP_GEMM_HALF128_MAX_M", 128);
         // split-K slabs: ONE block per CU, not three.  A slab costs 8 M N bytes (written here, read by the reduce or the consuming
         // kernel) against N K / splits weight bytes -- at M = 64 and K / splits = 683 that is 0.75 extra bytes per weight byte, and it
         // is written when all blocks finish together.  Measured on the 7B shapes, HBM-cold (profiles/r04_splitk_sweep.log): w13 at
         // M = 64 with 5 / 1 slabs 37.6 / 29.9 us (and no reduce kernel), wqkv 6 / 2 slabs 25.1 / 20.7 us; wo / w2 (32 tiles) keep 8
-        static const int h_blocks = getenv("PPLHIP_GEMM_HALF128_BLOCKS") ? atoi(getenv("PPLHIP_GEMM_HALF128_BLOCKS")) : 256;
+        static const int h_blocks = tune_int("PPLHIP_GEMM_HALF128_BLOCKS", 256);
         int sp = splits;
         const int kt128 = K / (G_BK * S_KS);
         if (ws && forced_split <= 0) {
@@ -862,7 +862,7 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
             while (sp > 1 && (size_t)sp * M * N * sizeof(float) > ws_bytes) --sp;
         }
         if (sp > kt128) sp = kt128 > 0 ? kt128 : 1;
-        static const int half128_unsplit_max_m = getenv("PPLHIP_GEMM_HALF128_UNSPLIT_MAX_M") ? atoi(getenv("PPLHIP_GEMM_HALF128_UNSPLIT_MAX_M")) : 80;  // (w13: 80-row sub-tile 31.0-31.6 vs 32.4-32.6 us at M = 72-80, 96 rows 34.4 vs 33.1)
+        static const int half128_unsplit_max_m = tune_int("PPLHIP_GEMM_HALF128_UNSPLIT_MAX_M", 80);  // (w13: 80-row sub-tile 31.0-31.6 vs 32.4-32.6 us at M = 72-80, 96 rows 34.4 vs 33.1)
         if (half128 && (half || (M <= 128 && M <= half128_max_m && (sp > 1 || M <= half128_unsplit_max_m) && m_tiles == 1)) && wq_bit == 8 && K % (G_BK * S_KS) == 0) {
             const int kt_per128 = (kt128 + sp - 1) / sp;
             sp = (kt128 + kt_per128 - 1) / kt_per128;
@@ -894,7 +894,7 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
             return launch_splitk_reduce(s, ws, sp, M, N, scale, y, ldy, epi);
         }
         // W4 with K slabs of at most 32 tiles (16 quantisation groups): the scale area shrinks from 16 to 4 KiB and three blocks fit a CU
-        static const int w4_sc16 = getenv("PPLHIP_GEMM_W4_SC16") ? atoi(getenv("PPLHIP_GEMM_W4_SC16")) : 1;
+        static const int w4_sc16 = tune_int("PPLHIP_GEMM_W4_SC16", 1);
         const bool w4_small_sc = w4_sc16 && wq_bit == 4 && splits > 1 && kt_per <= 32 && wl == 1 && !half && stages == 2;
 #define DMA_LAUNCH(WQ, O32, ST)                                                                                     \
     do { if constexpr (WQ == 8 && ST >= 3) { if (wl == 6) { hipLaunchKernelGGL((gemm_dma_kernel<WQ, O32, ST, 6>), g2, dim3(768), 0, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles, map_mode, kt_per, ws); break; } } \

@@ -585,7 +585,7 @@ hipError_t launch_linear_i8(hipStream_t s, const int8_t* xq, const float* sx, co
     if (swiglu && out_fp32) return hipErrorInvalidValue;
     if (N % 4 || ldy % 4 || K % 16) return hipErrorInvalidValue;
     const int epi = swiglu ? EPI_SWIGLU : (out_fp32 ? EPI_F32 : EPI_F16);
-    static const bool force_generic = getenv("PPLHIP_GEMM_GENERIC") != nullptr;
+    static const bool force_generic = tune_set("PPLHIP_GEMM_GENERIC");
     if (M > 32 && K % I_BK == 0 && !force_generic) {
         const int n_tiles = (N + I_BN - 1) / I_BN, m_tiles = (int)((M + I_BM - 1) / I_BM);
         const size_t lds = 4 * (size_t)I_BM * I_BK;
@@ -602,10 +602,10 @@ hipError_t launch_linear_i8(hipStream_t s, const int8_t* xq, const float* sx, co
         // 8-wave producer / consumer blocks everywhere (measured at M = 1024 against the 4-wave kernel: wo 32.5 -> 28.6 us and
         // w2 76.0 -> 51.4 us with a 4-stage ring, one block per CU; w13 116.6 -> 106.0 us with two stages, two blocks per CU; wqkv
         // 62.1 vs 63.6 us; M = 2048 layer 502 -> 459 us, M = 8192 equal).  PPLHIP_GEMM_I8_PC = 0 (4-wave kernel) / 2 / 3 / 4 forces a form.
-        static const int min_m256 = getenv("PPLHIP_GEMM_I8_256_MIN_M") ? atoi(getenv("PPLHIP_GEMM_I8_256_MIN_M")) : 4096;  // measured: M = 4096 layer 888 us (1.87 POP/s) vs 1110, M = 2048 554 vs 459 us
+        static const int min_m256 = tune_int("PPLHIP_GEMM_I8_256_MIN_M", 4096);  // measured: M = 4096 layer 888 us (1.87 POP/s) vs 1110, M = 2048 554 vs 459 us
         if (M >= min_m256 && N >= 1024) {
             const int nt2 = (N + 255) / 256, mt2 = (int)((M + 255) / 256);
-            static const int st256 = getenv("PPLHIP_GEMM_I8_256_ST") ? atoi(getenv("PPLHIP_GEMM_I8_256_ST")) : 4;
+            static const int st256 = tune_int("PPLHIP_GEMM_I8_256_ST", 4);
             const size_t lds2 = (size_t)(st256 == 3 ? 3 : 4) * 2 * 256 * 64;
             static bool attr2[64] = {false};
             if (!attr2[dev & 63]) {
@@ -615,8 +615,8 @@ hipError_t launch_linear_i8(hipStream_t s, const int8_t* xq, const float* sx, co
 #undef A2
                 attr2[dev & 63] = true;
             }
-            static const int forced_gm = getenv("PPLHIP_GEMM256_GM") ? atoi(getenv("PPLHIP_GEMM256_GM")) : 0;
-            static const int forced_gn = getenv("PPLHIP_GEMM256_GN") ? atoi(getenv("PPLHIP_GEMM256_GN")) : 0;
+            static const int forced_gm = tune_int("PPLHIP_GEMM256_GM", 0);
+            static const int forced_gn = tune_int("PPLHIP_GEMM256_GN", 0);
             const int nl = (nt2 + 7) / 8;
             int gm = forced_gm > 0 ? forced_gm : 4;
             while (gm > 1 && mt2 % gm) --gm;
@@ -630,7 +630,7 @@ hipError_t launch_linear_i8(hipStream_t s, const int8_t* xq, const float* sx, co
             return hipGetLastError();
         }
         {   // 128 x 384 tiles when they fill rounds of 256 one-per-CU blocks (the rule of linear_w8_wide_waves, k_gemm_wide.hip)
-            static const int wide = getenv("PPLHIP_GEMM_I8_WIDE") ? atoi(getenv("PPLHIP_GEMM_I8_WIDE")) : 1;
+            static const int wide = tune_int("PPLHIP_GEMM_I8_WIDE", 1);
             if (wide && M >= 512 && N >= 8192 && linear_w8_wide_waves(M, N) == 12) {
                 const int ntw = (N + IW_BN - 1) / IW_BN, mtw = (int)((M + I_BM - 1) / I_BM);
                 const size_t ldsw = (size_t)IW_ST * (IW_XB + IW_WB);
@@ -648,7 +648,7 @@ hipError_t launch_linear_i8(hipStream_t s, const int8_t* xq, const float* sx, co
                 return hipGetLastError();
             }
         }
-        static const int forced_pc = getenv("PPLHIP_GEMM_I8_PC") ? atoi(getenv("PPLHIP_GEMM_I8_PC")) : -1;
+        static const int forced_pc = tune_int("PPLHIP_GEMM_I8_PC", -1);
         const int pc = forced_pc >= 0 ? forced_pc : ((int64_t)n_tiles * m_tiles <= 256 ? 4 : 2);
         if (pc == 2 || pc == 3 || pc == 4) {
             const size_t lds_pc = (size_t)pc * 2 * I_BM * I_BK;

@@ -45,33 +45,16 @@ __device__ __forceinline__ void gv_unpack(const uint4& raw, h2 sc, h8* out) {
     }
 }
 
-// NORM: x is the residual stream h; the kernel multiplies rmsnorm(h + skip) * norm_w (K2 fused into the GEMV that consumes it: every block
-// re-derives the row scale from the 8 KiB row -- L2 traffic, one launch and one 4 us kernel boundary less per norm, GemvFuse below).
-// Arithmetic and summation order of rmsnorm_kernel (k_elem.hip), so that fused and unfused steps agree bit for bit.
-template <int WQ, int M, int EPI, int NW, bool NORM>  // NW waves per block (4 or 8)
+// (Round 4 also had a form with the consuming RMSNorm folded in -- bit-identical and measured slower, batch 1 2.42 -> 2.62 ms: every one of
+// the ~768 short blocks paid the row reduction in front of its first product; removed in round 5.)
+template <int WQ, int M, int EPI, int NW>  // NW waves per block (4 or 8)
 __global__ __launch_bounds__(NW * 64) void gemv_stream_kernel(const uint16_t* __restrict__ x, const void* __restrict__ wv,
                                                               const uint16_t* __restrict__ scale, int N, int K, int group,
-                                                              void* __restrict__ yv, int64_t ldy, int nwk_log2, int npw, int nb, GemvFuse f) {
+                                                              void* __restrict__ yv, int64_t ldy, int nwk_log2, int npw, int nb) {
     using C = GvCfg<WQ>;
     constexpr int KL = C::KL, KP = C::KP, NV = KL / 8;
     __shared__ float red[NW][GV_RB][M];
-    __shared__ float nred[M][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // side job (any launch): the residual update a fused norm left undone, res_h := fp16(res_h + res_skip), a few KiB spread over the grid
-    if (f.res_h) {
-        for (int c = blockIdx.x * (NW * 64) + tid; c < f.res_chunks; c += gridDim.x * (NW * 64)) {
-            float a[8], b[8];
-            unpack8(reinterpret_cast<const uint4*>(f.res_h)[c], a);
-            unpack8(reinterpret_cast<const uint4*>(f.res_skip)[c], b);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] = round_h(a[j] + b[j]);
-            reinterpret_cast<uint4*>(f.res_h)[c] = pack8(a);
-        }
-    }
-    float inv[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) inv[m] = 1.f;
-    bool inv_ready = !NORM;
     // waves along K (a row's pieces p == wk (mod nwk)) x waves along rows (8 nb rows each): short rows (few pieces) give the spare waves
     // rows of their own instead of leaving them idle.  npw = pieces per wave and row, nb = batches of 8 rows per wave (1 or 2: fewer rows per
     // wave when the matrix is small, so that every CU still gets several waves)
@@ -103,64 +86,13 @@ __global__ __launch_bounds__(NW * 64) void gemv_stream_kernel(const uint16_t* __
                     sc[u] = h2{(_Float16)1, (_Float16)1};
                 }
             }
-            if constexpr (NORM) {
-                if (!inv_ready) {   // (behind the first weight loads: their latency covers it)
-                    const int chunks = K / 8;
-                    float ss[M];
-#pragma unroll
-                    for (int m = 0; m < M; ++m) ss[m] = 0.f;
-                    if (tid < 256) {
-                        for (int c = tid; c < chunks; c += 256) {
-#pragma unroll
-                            for (int m = 0; m < M; ++m) {
-                                float a[8];
-                                unpack8(reinterpret_cast<const uint4*>(x + (int64_t)m * K)[c], a);
-                                if (f.skip) {
-                                    float b[8];
-                                    unpack8(reinterpret_cast<const uint4*>(f.skip + (int64_t)m * K)[c], b);
-#pragma unroll
-                                    for (int j = 0; j < 8; ++j) a[j] = round_h(a[j] + b[j]);
-                                }
-#pragma unroll
-                                for (int j = 0; j < 8; ++j) ss[m] += a[j] * a[j];
-                            }
-                        }
-#pragma unroll
-                        for (int m = 0; m < M; ++m) {
-                            ss[m] = wave_sum(ss[m]);
-                            if (lane == 0) nred[m][wave] = ss[m];
-                        }
-                    }
-                    __syncthreads();
-#pragma unroll
-                    for (int m = 0; m < M; ++m) inv[m] = 1.0f / sqrtf((nred[m][0] + nred[m][1] + nred[m][2] + nred[m][3]) / (float)K + f.eps);
-                    inv_ready = true;
-                }
-            }
             // activations of the chunk, packed fp16 (L1 / L2 resident: M rows of K halfs)
             h8 xv[M][NV];
 #pragma unroll
             for (int m = 0; m < M; ++m)
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
-                    if constexpr (NORM) {
-                        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, wn[8];
-                        if (live) {
-                            unpack8(*reinterpret_cast<const uint4*>(x + (int64_t)m * K + k0 + v * 8), a);
-                            if (f.skip) {
-                                float b[8];
-                                unpack8(*reinterpret_cast<const uint4*>(f.skip + (int64_t)m * K + k0 + v * 8), b);
-#pragma unroll
-                                for (int j = 0; j < 8; ++j) a[j] = round_h(a[j] + b[j]);
-                            }
-                            unpack8(*reinterpret_cast<const uint4*>(f.norm_w + k0 + v * 8), wn);
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) a[j] = a[j] * inv[m] * wn[j];
-                        }
-                        xv[m][v] = __builtin_bit_cast(h8, pack8(a));
-                    } else {
-                        xv[m][v] = live ? __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(x + (int64_t)m * K + k0 + v * 8)) : h8{0, 0, 0, 0, 0, 0, 0, 0};
-                    }
+                    xv[m][v] = live ? __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(x + (int64_t)m * K + k0 + v * 8)) : h8{0, 0, 0, 0, 0, 0, 0, 0};
                 }
             float part[GV_U][M];
 #pragma unroll
@@ -259,11 +191,7 @@ int gemv_stream_max_m(int wq_bit, int group, int N, int K) {
 }
 
 hipError_t launch_gemv_stream(hipStream_t s, const uint16_t* x, const void* w, const uint16_t* scale, int wq_bit, int group, int64_t M, int N,
-                              int K, void* y, int64_t ldy, int epi, const GemvFuse* fuse) {
-    GemvFuse f;
-    if (fuse) f = *fuse;
-    const bool norm = f.norm_w != nullptr;
-    if (norm && (K % 8 || K > 256 * 8 * 64)) return hipErrorInvalidValue;
+                              int K, void* y, int64_t ldy, int epi) {
     const int kl = wq_bit == 8 ? 16 : (wq_bit == 4 ? 32 : 8);
     const int pieces = (K / kl + 63) / 64;
     int nwk_log2 = 0;
@@ -275,9 +203,8 @@ hipError_t launch_gemv_stream(hipStream_t s, const uint16_t* x, const void* w, c
     const int nb = waves16 >= 2048 ? 2 : 1;
     const int rows = (nw / nwk) * nb * GV_U;
     dim3 grid((unsigned)((N + rows - 1) / rows)), block(nw * 64);
-#define GV_L(WQ, MM, E, W, NR) hipLaunchKernelGGL((gemv_stream_kernel<WQ, MM, E, W, NR>), grid, block, 0, s, x, w, scale, N, K, group, y, ldy, nwk_log2, npw, nb, f)
-#define GV_P(WQ, MM, E) do { if (norm) { if (nw == 4) GV_L(WQ, MM, E, 4, true); else GV_L(WQ, MM, E, 8, true); } \
-                             else { if (nw == 4) GV_L(WQ, MM, E, 4, false); else GV_L(WQ, MM, E, 8, false); } } while (0)
+#define GV_L(WQ, MM, E, W) hipLaunchKernelGGL((gemv_stream_kernel<WQ, MM, E, W>), grid, block, 0, s, x, w, scale, N, K, group, y, ldy, nwk_log2, npw, nb)
+#define GV_P(WQ, MM, E) do { if (nw == 4) GV_L(WQ, MM, E, 4); else GV_L(WQ, MM, E, 8); } while (0)
 #define GV_E(WQ, MM) do { if (epi == EPI_F32) GV_P(WQ, MM, EPI_F32); else if (epi == EPI_F16) GV_P(WQ, MM, EPI_F16); else GV_P(WQ, MM, EPI_SWIGLU); } while (0)
 #define GV_M(WQ) do { if (M == 1) GV_E(WQ, 1); else if (M == 2) GV_E(WQ, 2); else if (M == 3) GV_E(WQ, 3); else GV_E(WQ, 4); } while (0)
     if (M < 1 || M > 4 || npw > 3) return hipErrorInvalidValue;

@@ -123,21 +123,8 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
 hipError_t launch_splitk_reduce(hipStream_t s, const float* ws, int splits, int64_t M, int N, const uint16_t* scale, void* y, int64_t ldy, int epi);
 // ---- k_gemv.hip: streaming GEMV, 1 <= M <= 4 (whole 1-KiB row pieces per wave-load; VALU dot products) ----------------------------
 int gemv_stream_max_m(int wq_bit, int group, int N, int K);  // largest M the kernel takes for this shape (0: none)
-// optional fusions of a small-batch decode step (tensor-parallel size 1):
-//   norm_w != NULL: x is the residual stream and the kernel multiplies rmsnorm(x + skip) * norm_w (skip may be NULL) -- K2 folded into the
-//                   consuming GEMV; the residual stream itself is NOT updated by that launch ...
-//   res_h != NULL : ... but by a later one as a side job: res_h[i] := fp16(res_h[i] + res_skip[i]) for res_chunks 16-byte chunks
-//                   (the launch that follows the last reader of the old value: wo / w2)
-struct GemvFuse {
-    const uint16_t* skip = nullptr;
-    const uint16_t* norm_w = nullptr;
-    float eps = 0.f;
-    uint16_t* res_h = nullptr;
-    const uint16_t* res_skip = nullptr;
-    int res_chunks = 0;
-};
 hipError_t launch_gemv_stream(hipStream_t s, const uint16_t* x, const void* w, const uint16_t* scale, int wq_bit, int group, int64_t M, int N,
-                              int K, void* y, int64_t ldy, int epi, const GemvFuse* fuse = nullptr);
+                              int K, void* y, int64_t ldy, int epi);
 // ---- k_gemm_i8.hip: online_i8i8 (W8A8) ------------------------------------------------------------
 // per-token int8 activations: q [M, ldq] (columns K..ldq-1 zeroed), sx [M] = max|x| / 127
 hipError_t launch_quant_act(hipStream_t s, const uint16_t* x, int64_t M, int K, int64_t ldx, int8_t* q, int64_t ldq, float* sx);

@@ -92,7 +92,6 @@ struct Rank {
     int64_t* pages_host = nullptr;  // pinned
     uint64_t pages_cap = 0;
     int64_t B = 0, T = 0, decoding_batches = 0, max_seq_len = 0, max_kv_len = 0, max_pages = 0;
-    int64_t total_kv = 0;  // kv_starts[B]: sum of the requests' kv lengths of this step
     // split-K results left unreduced for the kernel that consumes them (kernels.h SplitSlabs): wqkv -> RoPE + KV write, wo -> FFN norm,
     // w2 -> the next layer's attention norm (or the final norm)
     SplitSlabs sl_qkv, sl_part, sl_part2;
@@ -171,8 +170,17 @@ struct pplhip_ctx {
     bool p2p_connected = false;
     uint64_t p2p_timeout_ticks = 0;  // s_memrealtime ticks (100 MHz)
     // PPLHIP_DUAL_STREAM=1: pure-decode steps of dual_min_rows..dual_max_rows rows as two half-batches on two streams (run_launches)
-    int dual_mode = 0;
+    // -1 (default): automatic -- under real tensor parallelism (a communicator over >= 2 ranks) pure-decode steps of 512..1024 rows run as
+    // two half-batches on two streams, so that each half's all-reduces overlap the other half's matmuls (the north star's schedule;
+    // +0.25 ms of compute per 1024-row 7B / TP8 step against ~2.2 ms of link time, profiles/r04_late_experiments.md 1); config 4's 256
+    // rows stay on one stream (halves of 128 rows measured -8 %).  Automatic only on the direct collectives (two channels, validated on
+    // one device at tp 2 / 4): two RCCL communicators running concurrently on one device have never run on >= 2 devices, so a
+    // group that fell back to RCCL keeps one stream unless PPLHIP_DUAL_STREAM=1 asks for it.  1: rows dual_min_rows..dual_max_rows at any tp; 0: never
+    int dual_mode = -1;
+    bool dual_auto = false;          // the automatic rule is in force (row window 512..1024)
     int64_t dual_min_rows = 96, dual_max_rows = 512;
+    int selftest = 0;                // direct collectives' start-up self-test: 0 not run, 1 passed on every rank, -1 failed (RCCL in charge)
+    std::string comm_notes;          // every fallback taken at start-up, in order (never silent: also on stderr)
     bool graph_on = false;           // PPLHIP_DECODE_GRAPH=1: replay pure-decode steps as HIP graphs (opt-in, see run_decode_graph)
     int64_t graph_max_batch = 64;    // above this a step is seconds of GPU work per thousand launches: nothing to gain
     int H = 0, Hkv = 0, D = 0, inter = 0, vocab_local = 0;
@@ -182,11 +190,22 @@ struct pplhip_ctx {
 
 namespace {
 
+bool verbose() {   // PPLHIP_VERBOSE: messages on stderr (errors, the collectives' choice, graph capture)
+    static const bool on = getenv("PPLHIP_VERBOSE") != nullptr;
+    return on;
+}
+
+// a fallback was taken (direct collectives -> RCCL, two streams -> one): always on stderr, and kept for pplhip_comm_info
+void comm_note(pplhip_ctx* c, const std::string& msg) {
+    fprintf(stderr, "[pplhip] %s\n", msg.c_str());
+    if (c) { if (!c->comm_notes.empty()) c->comm_notes += "; "; c->comm_notes += msg; }
+}
+
 int fail(pplhip_ctx* c, int rank, int code, const std::string& msg) {
     if (c) {
         if (rank >= 0 && rank < (int)c->ranks.size()) c->ranks[rank].err = msg; else c->err = msg;
     }
-    if (getenv("PPLHIP_VERBOSE")) fprintf(stderr, "[pplhip] error %d (rank %d): %s\n", code, rank, msg.c_str());
+    if (verbose()) fprintf(stderr, "[pplhip] error %d (rank %d): %s\n", code, rank, msg.c_str());
     return code;
 }
 
@@ -304,7 +323,9 @@ int decode_split(const pplhip_ctx* c, int64_t nb, int64_t max_kv_len) {
         int64_t want = (512 + blocks - 1) / blocks;            // aim for >= 512 workgroups
         // >= 256 tokens per split; >= 128 when there are very few blocks (batch 1-4 of a multi-head model: kv 512 split 4 8.6 us against 10.3 us
         // with split 2, kv 2048 split 8 11.0 against 13.8 with 4 -- one memory round trip per wave instead of two, round 4)
-        int64_t cap = std::max<int64_t>(1, blocks <= 128 ? std::min<int64_t>(max_kv_len / 128, 8) : max_kv_len / 256);
+        // (never below the >= 256-tokens rule: at kv 8192 a single stream keeps split 16 / 32 -- ADVICE r4: the 8-way limit of the
+        // 128-token rule had lowered it to 8 from kv 2048 on)
+        int64_t cap = std::max<int64_t>(1, std::max<int64_t>(max_kv_len / 256, blocks <= 128 ? std::min<int64_t>(max_kv_len / 128, 8) : 0));
         split = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want, cap), 32));
         if (mode == 2 && split < 2 && max_kv_len >= 64) split = 2;
     }
@@ -316,7 +337,8 @@ int decode_split(const pplhip_ctx* c, int64_t nb, int64_t max_kv_len) {
 // the direct path cannot be used: an error when it was demanded (or no RCCL communicator exists), else RCCL stays in charge
 int p2p_unavailable(pplhip_ctx* c, int rank, const std::string& why) {
     if (c->comm_want == 2 || c->comm_mode != 1) return fail(c, rank, PPLHIP_DEVICE_RUNTIME_ERROR, "direct collectives unavailable: " + why);
-    if (getenv("PPLHIP_VERBOSE")) fprintf(stderr, "[pplhip] direct collectives unavailable (%s): using RCCL\n", why.c_str());
+    c->selftest = -1;
+    comm_note(c, "direct collectives unavailable (" + why + "): RCCL takes over");
     return 0;
 }
 
@@ -430,7 +452,8 @@ int p2p_selftest(pplhip_ctx* c, const std::string* local_failure = nullptr) {
         return p2p_unavailable(c, 0, "self-test: " + why);
     }
     c->comm_mode = 2;
-    if (getenv("PPLHIP_VERBOSE")) fprintf(stderr, "[pplhip] direct collectives over peer-mapped memory: self-test passed on %d local rank(s) of %d\n", n, tp);
+    c->selftest = 1;
+    if (verbose()) fprintf(stderr, "[pplhip] direct collectives over peer-mapped memory: self-test passed on %d local rank(s) of %d\n", n, tp);
     return 0;
 }
 
@@ -556,7 +579,7 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
     const int tp = opts->world_size > 0 ? opts->world_size : n;
     c->tp = tp;
     const pplhip_model_desc& d = c->d;
-    auto bad = [&](const char* m) { if (getenv("PPLHIP_VERBOSE")) fprintf(stderr, "[pplhip] init: %s\n", m); return PPLHIP_INVALID_VALUE; };
+    auto bad = [&](const char* m) { if (verbose()) fprintf(stderr, "[pplhip] init: %s\n", m); return PPLHIP_INVALID_VALUE; };
     if (n < 1 || tp < n || opts->rank_base < 0 || opts->rank_base + n > tp) return bad("rank layout");
     if (d.num_heads <= 0 || d.hidden_dim % d.num_heads) return bad("heads");
     if (d.num_heads % tp || d.num_kv_heads % tp || d.intermediate_dim % tp || d.vocab_size % tp) return bad("tp divisibility");
@@ -600,6 +623,11 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
     c->tp_on = want_comm;
     if (const char* e = getenv("PPLHIP_DECODE_GRAPH")) c->graph_on = atoi(e) != 0;
     if (const char* e = getenv("PPLHIP_DUAL_STREAM")) c->dual_mode = atoi(e);
+    if (c->dual_mode < 0) {   // automatic: only where there is link time to hide
+        c->dual_auto = tp > 1 && !getenv("PPLHIP_EMULATE_TP");
+        c->dual_mode = c->dual_auto ? 1 : 0;
+        if (c->dual_auto) { c->dual_min_rows = 512; c->dual_max_rows = 1024; }
+    }
     if (const char* e = getenv("PPLHIP_DUAL_MIN_ROWS")) c->dual_min_rows = std::max(2, atoi(e));
     if (const char* e = getenv("PPLHIP_DUAL_MAX_ROWS")) c->dual_max_rows = atoi(e);
     if (const char* e = getenv("PPLHIP_DECODE_GRAPH_MAX_BATCH")) c->graph_max_batch = std::max(1, atoi(e));
@@ -643,10 +671,17 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
         for (int r = 0; r < n; ++r) c->ranks[r].comm = comms[r];
         if (c->dual_mode) {   // a second communicator over the same ranks for the second stream of a two-stream decode step
             std::vector<ncclComm_t> comms2(n, nullptr);
-            NCCLCK(cp, -1, ncclGroupStart());
-            for (int r = 0; r < n; ++r) NCCLCK(cp, -1, ncclCommSplit(comms[r], 0, opts->rank_base + r, &comms2[r], nullptr));
-            NCCLCK(cp, -1, ncclGroupEnd());
-            for (int r = 0; r < n; ++r) c->ranks[r].comm2 = comms2[r];
+            ncclResult_t rc2 = ncclGroupStart();
+            for (int r = 0; r < n && rc2 == ncclSuccess; ++r) rc2 = ncclCommSplit(comms[r], 0, opts->rank_base + r, &comms2[r], nullptr);
+            const ncclResult_t rc3 = ncclGroupEnd();
+            if (rc2 == ncclSuccess && rc3 == ncclSuccess) {
+                for (int r = 0; r < n; ++r) c->ranks[r].comm2 = comms2[r];
+            } else {
+                // ladder: without a second communicator a two-stream step can still run on the direct collectives (their second channel);
+                // on RCCL it falls back to one stream (run_launches checks R.comm2)
+                comm_note(c.get(), std::string("second RCCL communicator unavailable (") + ncclGetErrorString(rc2 != ncclSuccess ? rc2 : rc3) +
+                                       "): two-stream decode only on the direct collectives, else one stream");
+            }
         }
         c->comm_mode = 1;
     }
@@ -1130,7 +1165,6 @@ int pplhip_set_inputs(pplhip_ctx* c, int rank, const pplhip_step* st) {
     memcpy(hbuf + off, st->token_inputs, T * 8); R.d_tok = R.step_dev + off; off += T;
     memcpy(hbuf + off, st->seq_starts, (B + 1) * 8); R.d_seq = R.step_dev + off; R.h_seq = hbuf + off; off += B + 1;
     memcpy(hbuf + off, st->kv_starts, (B + 1) * 8); R.d_kvs = R.step_dev + off; off += B + 1;
-    R.total_kv = st->kv_starts[B] - st->kv_starts[0];
     memcpy(hbuf + off, st->start_pos, B * 8); R.d_sp = R.step_dev + off; off += B;
     if (c->d.cache_mode == 0) {
         if (B > 0 && !st->cache_indices) return PPLHIP_INVALID_VALUE;
@@ -1186,17 +1220,6 @@ static int layer_linear(pplhip_ctx* c, int rank, const Linear& l, const uint16_t
     return 0;
 }
 
-// Small-batch decode steps (<= 4 token rows, tensor-parallel size 1, weight-only quantisation): the two RMSNorms of a layer are folded into
-// the streaming GEMVs that consume them (k_gemv.hip, GemvFuse) and the residual update they would have written is done as a side job of
-// the following row-parallel GEMV (wo: h += previous layer's FFN output; w2: h += attention output) -- 64 launches of ~4 us less per
-// 7B step.  Bit-identical to the unfused step (same arithmetic, same order) -- and MEASURED SLOWER: every one of the ~768 short blocks of a
-// GEMV pays the row reduction (an L2 round trip, a barrier) in front of its first product: batch 1 2.42 -> 2.62 ms, batch 4 3.01 -> 4.28 ms
-// (gpurun_out/small_batch_2.log, round 4).  Kept behind PPLHIP_FUSE_NORM=1 with its test; not the default.
-static bool fuse_small_step(const pplhip_ctx* c, const Linear& l, int64_t rows) {
-    static const int on = getenv("PPLHIP_FUSE_NORM") ? atoi(getenv("PPLHIP_FUSE_NORM")) : 0;  // measured slower (below): off
-    return on && c->tp == 1 && c->d.act_quant_bit != 8 && rows >= 1 && rows <= gemv_stream_max_m(l.qbit, l.group, l.N, l.Kp) && l.Kp == c->d.hidden_dim;
-}
-
 // attention block of layer l for one chunk: (Skip)RMSNorm -> wqkv -> RoPE + KV write -> attention -> wo (partial sums)
 static int layer_attention_part(pplhip_ctx* c, int rank, int l, const Chunk& k, const uint16_t* pending, int split, int threads) {
     Rank& R = c->ranks[rank];
@@ -1209,16 +1232,7 @@ static int layer_attention_part(pplhip_ctx* c, int rank, int l, const Chunk& k, 
     uint16_t* h = R.h + k.t0 * hd;
     uint16_t* xn = R.xn + k.t0 * hd;
     const bool a8 = d.act_quant_bit == 8;  // the norm writes the int8 operand of the next linear directly (no fp16 xn, no separate pass)
-    const bool fuse = fuse_small_step(c, L.wqkv, k.tn) && fuse_small_step(c, L.w13, k.tn) && k.t0 == 0;
-    if (fuse) {
-        GemvFuse f;
-        f.skip = pending;
-        f.norm_w = L.attn_norm;
-        f.eps = d.norm_eps;
-        prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-        HIPCK(c, rank, launch_gemv_stream(s, h, L.wqkv.w, L.wqkv.scale, L.wqkv.qbit, L.wqkv.group, k.tn, L.wqkv.N, L.wqkv.Kp, R.qkv, L.wqkv.N, 0, &f));
-        prof_end(R, &ev);
-    } else {
+    {
         HIPCK(c, rank, launch_rmsnorm(s, h, pending ? pending + k.t0 * hd : nullptr, L.attn_norm, d.norm_eps, k.tn, hd, nullptr, xn,
                                       pending ? h : nullptr, a8 ? R.xq : nullptr, a8 ? R.sx : nullptr, pending ? &R.sl_part2 : nullptr));
         R.sl_part2 = SplitSlabs{};
@@ -1262,12 +1276,7 @@ static int layer_attention_part(pplhip_ctx* c, int rank, int l, const Chunk& k, 
         prof_end(R, &ev);
     }
     prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-    if (fuse && k.tn <= gemv_stream_max_m(L.wo.qbit, L.wo.group, L.wo.N, L.wo.Kp)) {
-        GemvFuse f;   // side job: the residual update the fused attention norm skipped (h += previous layer's FFN output)
-        if (pending) { f.res_h = h; f.res_skip = pending; f.res_chunks = (int)(k.tn * hd / 8); }
-        HIPCK(c, rank, launch_gemv_stream(s, R.att, L.wo.w, L.wo.scale, L.wo.qbit, L.wo.group, k.tn, L.wo.N, L.wo.Kp, R.part, hd, 0, &f));
-    } else {
-        if (fuse && pending) HIPCK(c, rank, launch_rmsnorm(s, h, pending, L.attn_norm, d.norm_eps, k.tn, hd, nullptr, xn, h));  // (wo not on the GEMV: plain update)
+    {
         int rc = layer_linear(c, rank, L.wo, R.att + k.t0 * (int64_t)H * D, k.tn, R.part + k.t0 * hd, hd, false, false, &R.sl_part);
         if (rc) return rc;
     }
@@ -1287,23 +1296,6 @@ static int layer_ffn_part(pplhip_ctx* c, int rank, int l, const Chunk& k) {
     uint16_t* xn = R.xn + k.t0 * hd;
     uint16_t* act = R.act + k.t0 * (int64_t)L.w2.Kp;
     const bool a8 = d.act_quant_bit == 8;
-    const bool fuse = fuse_small_step(c, L.wqkv, k.tn) && fuse_small_step(c, L.w13, k.tn) && k.t0 == 0 &&
-                      k.tn <= gemv_stream_max_m(L.w2.qbit, L.w2.group, L.w2.N, L.w2.Kp);
-    if (fuse) {
-        GemvFuse f;
-        f.skip = R.part;
-        f.norm_w = L.ffn_norm;
-        f.eps = d.norm_eps;
-        prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-        HIPCK(c, rank, launch_gemv_stream(s, h, L.w13.w, L.w13.scale, L.w13.qbit, L.w13.group, k.tn, L.w13.N, L.w13.Kp, act, L.w2.Kp, 2, &f));
-        prof_end(R, &ev);
-        GemvFuse g;   // side job of w2: h += attention output
-        g.res_h = h; g.res_skip = R.part; g.res_chunks = (int)(k.tn * hd / 8);
-        prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
-        HIPCK(c, rank, launch_gemv_stream(s, act, L.w2.w, L.w2.scale, L.w2.qbit, L.w2.group, k.tn, L.w2.N, L.w2.Kp, R.part2, hd, 0, &g));
-        prof_end(R, &ev);
-        return 0;
-    }
     HIPCK(c, rank, launch_rmsnorm(s, h, R.part + k.t0 * hd, L.ffn_norm, d.norm_eps, k.tn, hd, nullptr, xn, h, a8 ? R.xq : nullptr,
                                   a8 ? R.sx : nullptr, &R.sl_part));
     R.sl_part = SplitSlabs{};
@@ -1416,7 +1408,7 @@ static int run_launches(pplhip_ctx* c, int rank) {
     const bool identity_comm = comm && c->comm_mode != 2 && !R.comm;   // ranks emulated on one device (bench.py --emulate-tp)
     bool dual = false;
     if (c->dual_mode && R.stream2 && !ov && nb_decode == B && T == B && B >= c->dual_min_rows && B <= c->dual_max_rows && B >= 2 &&
-        (!comm || identity_comm || c->comm_mode == 2 || (R.comm && R.comm2)) && d.act_quant_bit != 8 && !R.dump_dev) {
+        (!comm || identity_comm || c->comm_mode == 2 || (R.comm && R.comm2 && !c->dual_auto)) && d.act_quant_bit != 8 && !R.dump_dev) {
         hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(R.stream, &cst);
         if (cst == hipStreamCaptureStatusNone) {
@@ -1425,8 +1417,8 @@ static int run_launches(pplhip_ctx* c, int rank) {
             ck[1] = Chunk{bm, B - bm, bm, B - bm, B - bm};
             nck = 2;
             dual = true;
-            static const bool verbose = getenv("PPLHIP_VERBOSE") != nullptr;
-            if (verbose && !R.dual_seen) {
+            static const bool verbose_ = verbose();
+            if (verbose_ && !R.dual_seen) {
                 R.dual_seen = true;
                 fprintf(stderr, "[pplhip] rank %d: two-stream decode (rows %lld + %lld)\n", rank, (long long)bm, (long long)(B - bm));
             }
@@ -1589,11 +1581,60 @@ static int run_decode_graph(pplhip_ctx* c, int rank, bool* done) {
         hipGraphDestroy(g);
         if (e2 != hipSuccess || !ex) { (void)hipGetLastError(); c->graph_on = false; return 0; }
         it->second.exec = ex;
-        if (getenv("PPLHIP_VERBOSE")) fprintf(stderr, "[pplhip] rank %d: decode step captured as a HIP graph (batch %lld, split %d, page-table width %lld)\n",
+        if (verbose()) fprintf(stderr, "[pplhip] rank %d: decode step captured as a HIP graph (batch %lld, split %d, page-table width %lld)\n",
                                               rank, (long long)B, (int)((key >> 24) & 0xff), (long long)R.max_pages);
     }
     HIPCK(c, rank, hipGraphLaunch(it->second.exec, R.stream));
     *done = true;
+    return 0;
+}
+
+int pplhip_comm_info(pplhip_ctx* c, int64_t rows, pplhip_comm_info_t* out) {
+    if (!c || !out) return PPLHIP_INVALID_VALUE;
+    memset(out, 0, sizeof(*out));
+    out->mode = c->comm_mode;
+    out->selftest = c->selftest;
+    out->has_rccl = !c->ranks.empty() && c->ranks[0].comm != nullptr;
+    out->dual_min_rows = c->dual_mode ? c->dual_min_rows : 0;
+    out->dual_max_rows = c->dual_mode ? c->dual_max_rows : 0;
+    // the schedule run_launches picks for a pure-decode step of `rows` rows (int8 activations, residual dumps and graph capture aside)
+    const Rank& R = c->ranks[0];
+    const bool two_chunks = c->tp_on && c->tp_overlap && rows >= c->tp_overlap_min_tokens && rows >= 2;
+    const bool two_streams = !two_chunks && c->dual_mode && R.stream2 && rows >= c->dual_min_rows && rows <= c->dual_max_rows && rows >= 2 &&
+                             (!c->tp_on || c->comm_mode == 2 || !R.comm || (R.comm && R.comm2 && !c->dual_auto)) && c->d.act_quant_bit != 8;
+    out->schedule = two_chunks ? 2 : (two_streams ? 1 : 0);
+    snprintf(out->notes, sizeof(out->notes), "%s", c->comm_notes.c_str());
+    return 0;
+}
+
+// one all-reduce of fp16 [rows, hidden], `iters` times back to back on the rank's stream, between two events.  Collective: every rank
+// of the group calls it with the same arguments.  path 0: the collectives in use; 1: RCCL (when a communicator exists)
+int pplhip_comm_allreduce_us(pplhip_ctx* c, int rank, int64_t rows, int32_t iters, int32_t path, float* us) {
+    if (!c || rank < 0 || rank >= (int)c->ranks.size() || !us || iters < 1 || rows < 1) return PPLHIP_INVALID_VALUE;
+    Rank& R = c->ranks[rank];
+    *us = -1.f;
+    if (!c->tp_on || rows > R.cap_T) return PPLHIP_INVALID_VALUE;
+    if (path == 1 && !R.comm) return 0;              // no RCCL communicator: nothing to compare with
+    if (path == 0 && c->comm_mode != 2 && !R.comm) return 0;
+    HIPCK(c, rank, hipSetDevice(R.device));
+    hipEvent_t e0, e1;
+    HIPCK(c, rank, hipEventCreate(&e0));
+    HIPCK(c, rank, hipEventCreate(&e1));
+    const int hd = c->d.hidden_dim;
+    const Chunk k{0, rows, 0, rows, rows};
+    for (int it = -2; it < iters; ++it) {            // two warm-up rounds
+        if (it == 0) HIPCK(c, rank, hipEventRecord(e0, R.stream));
+        if (path == 1) NCCLCK(c, rank, ncclAllReduce(R.part, R.part, (size_t)rows * hd, ncclFloat16, ncclSum, R.comm, R.stream));
+        else if (int rc = chunk_allreduce(c, rank, R.part, k, 0, false)) return rc;
+    }
+    HIPCK(c, rank, hipEventRecord(e1, R.stream));
+    HIPCK(c, rank, hipStreamSynchronize(R.stream));
+    float ms = 0.f;
+    HIPCK(c, rank, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *us = ms * 1e3f / (float)iters;
+    if (R.p2p_status && *R.p2p_status) return fail(c, rank, PPLHIP_DEVICE_RUNTIME_ERROR, "a direct collective timed out during pplhip_comm_allreduce_us");
     return 0;
 }
 

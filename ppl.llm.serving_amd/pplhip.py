@@ -69,10 +69,19 @@ class KvView(C.Structure):
                 ("layout", C.c_int32), ("mode", C.c_int32), ("page_size", C.c_int32), ("layer", C.c_int32)]
 
 
+COMM_MODES = {0: "none", 1: "rccl", 2: "direct xGMI kernels (two-shot, all links)"}
+COMM_SCHEDULES = {0: "one-stream (collectives in stream)", 1: "two-stream (half-batches, a channel each)", 2: "chunked (collectives on the communication stream)"}
+
+
+class CommInfo(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("selftest", C.c_int32), ("schedule", C.c_int32), ("has_rccl", C.c_int32),
+                ("dual_min_rows", C.c_int64), ("dual_max_rows", C.c_int64), ("notes", C.c_char * 512)]
+
+
 # every symbol include/pplhip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "pplhip_version", "pplhip_device_count", "pplhip_get_unique_id", "pplhip_init", "pplhip_destroy",
-    "pplhip_comm_export", "pplhip_comm_connect", "pplhip_comm_mode",
+    "pplhip_comm_export", "pplhip_comm_connect", "pplhip_comm_mode", "pplhip_comm_info", "pplhip_comm_allreduce_us",
     "pplhip_last_error", "pplhip_rank_load", "pplhip_rank_set_tensor", "pplhip_rank_init_synthetic",
     "pplhip_kv_block_bytes", "pplhip_kv_capacity", "pplhip_kv_alloc", "pplhip_kv_ptrs", "pplhip_kv_read",
     "pplhip_kv_write", "pplhip_kv_fill_synthetic", "pplhip_set_inputs", "pplhip_run", "pplhip_debug_run_dump", "pplhip_logits", "pplhip_copy_logits", "pplhip_sync",
@@ -103,6 +112,8 @@ def lib():
         L.pplhip_comm_export.argtypes = [vp, C.c_int, vp]
         L.pplhip_comm_connect.argtypes = [vp, vp]
         L.pplhip_comm_mode.argtypes = [vp]
+        L.pplhip_comm_info.argtypes = [vp, i64, C.POINTER(CommInfo)]
+        L.pplhip_comm_allreduce_us.argtypes = [vp, C.c_int, i64, i32, i32, C.POINTER(f32)]
         L.pplhip_rank_load.argtypes = [vp, C.c_int, C.c_char_p]
         L.pplhip_rank_set_tensor.argtypes = [vp, C.c_int, C.c_char_p, vp, u64]
         L.pplhip_rank_init_synthetic.argtypes = [vp, C.c_int, u64]
@@ -240,6 +251,20 @@ class Context:
 
     def comm_mode(self):
         return lib().pplhip_comm_mode(self.h)
+
+    def comm_info(self, rows):
+        """what a multi-GPU run does at a pure-decode step of `rows` rows: mode, self-test verdict, schedule, fallbacks taken"""
+        ci = CommInfo()
+        self._ck(lib().pplhip_comm_info(self.h, rows, C.byref(ci)), -1, "comm_info")
+        return {"mode": COMM_MODES[ci.mode], "selftest": {0: "not run", 1: "passed", -1: "failed"}[ci.selftest],
+                "schedule": COMM_SCHEDULES[ci.schedule], "rccl_communicator": bool(ci.has_rccl),
+                "two_stream_rows": [int(ci.dual_min_rows), int(ci.dual_max_rows)], "fallbacks": ci.notes.decode(errors="replace")}
+
+    def comm_allreduce_us(self, rows, iters=20, path=0, rank=0):
+        """average microseconds of one all-reduce of fp16 [rows, hidden] (collective call); None when the path does not exist"""
+        us = C.c_float(-1.0)
+        self._ck(lib().pplhip_comm_allreduce_us(self.h, rank, rows, iters, path, C.byref(us)), rank, "comm_allreduce_us")
+        return None if us.value < 0 else float(us.value)
 
     # weights
     def set_tensor(self, rank, name, arr):

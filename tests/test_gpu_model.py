@@ -361,12 +361,10 @@ def test_exported_hf_checkpoint_runs_on_the_device(tmp_path_factory):
 
 
 @pytest.mark.parametrize("wq,kvq,batch", [(8, 8, 1), (8, 8, 3), (4, 0, 2), (0, 0, 4), (8, 8, 5)])
-def test_small_batch_decode_with_norms_fused_into_the_streaming_gemv(wq, kvq, batch):
-    """decode steps of <= 4 rows: both RMSNorms of a layer are folded into the streaming GEMVs that consume them and the residual
-    updates ride on wo / w2 (pplhip.cc fuse_small_step, k_gemv.hip GemvFuse) -- against the oracle, and BIT-identical to the same steps
-    without the fusion.  The fusion is OFF by default (measured slower, pplhip.cc): the fused steps run in a child process with
-    PPLHIP_FUSE_NORM=1.  batch 5 = the unfused path on both sides as a control."""
-    import subprocess, sys
+def test_small_batch_decode_on_the_streaming_gemv(wq, kvq, batch):
+    """decode steps of 1..5 rows (the streaming GEMV of k_gemv.hip up to its row limit, the half-height tiles above it) against the oracle.
+    (Round 4 also ran these steps with both RMSNorms folded into the GEMVs -- bit-identical, measured slower; that variant and its switch
+    were removed in round 5.)"""
     m = load_pplhip()
     desc = ref.make_desc(hidden_dim=512, intermediate_dim=1408, num_layers=3, num_heads=4, num_kv_heads=4, vocab_size=1024,
                          max_position=512, cache_quant_bit=kvq, cache_quant_group=8 if kvq else 1, cache_layout=3,
@@ -381,30 +379,8 @@ def test_small_batch_decode_with_norms_fused_into_the_streaming_gemv(wq, kvq, ba
     prompts = [rng.randint(3, 1024, size=n) for n in (9, 4, 17, 1, 6)[:batch]]
     res = generate_both(m, ctx, [rm], desc, prompts, 5, 512)
     check_steps(res, k=1)
-    logits = np.stack([r[0] for r in res])
     ctx.close()
     rm.close()
-    code = ("import numpy as np, sys\n"
-            "from oracle import ref\n"
-            "from tests.conftest import load_pplhip\n"
-            "from tests.test_gpu_model import generate_both\n"
-            "m = load_pplhip()\n"
-            f"desc = ref.make_desc(hidden_dim=512, intermediate_dim=1408, num_layers=3, num_heads=4, num_kv_heads=4, vocab_size=1024, max_position=512, cache_quant_bit={kvq}, cache_quant_group={8 if kvq else 1}, cache_layout=3, cache_mode=0, weight_quant_bit={wq}, weight_quant_group=128)\n"
-            "rm = ref.RefModel(desc); rm.init_synthetic(99)\n"
-            "ctx = m.Context(m.copy_desc(desc), max_running_batch=8, max_tokens_per_step=64); ctx.init_synthetic(0, 99)\n"
-            "rm.kv_alloc(512); ctx.kv_alloc(0, 512)\n"
-            f"rng = np.random.RandomState({batch})\n"
-            f"prompts = [rng.randint(3, 1024, size=n) for n in (9, 4, 17, 1, 6)[:{batch}]]\n"
-            "res = generate_both(m, ctx, [rm], desc, prompts, 5, 512)\n"
-            "np.save(sys.argv[1], np.stack([r[0] for r in res]))\n")
-    with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "fused.npy")
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, PPLHIP_FUSE_NORM="1"), cwd=root, capture_output=True,
-                           text=True, timeout=600)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-        unfused = np.load(out)
-    assert (logits.view(np.uint32) == unfused.view(np.uint32)).all(), float(np.abs(logits - unfused).max())
 
 
 def _defer_case_logits(wq, kvq, batch, steps=3, hkv=16):

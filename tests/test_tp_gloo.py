@@ -145,6 +145,14 @@ def test_bench_control_plane_world_size_2_dry_run():
     res = json.loads(line[0])
     assert res["n_gpus"] == 2 and res["steps"] == 3 and res["warmup"] == 1 and res["scaling"] == "strong"
     assert res["dry_run"] is True and res["unique_id_agreed"] is True and res["config"]["parallelism"] == "tp2"
+    # the fields a multi-GPU run is diagnosed from: collectives' mode / self-test verdict / fallbacks / timed all-reduce
+    # of the step's own message on the chosen path and on RCCL, the step's schedule, slowest and fastest rank
+    co = res["collectives"]
+    assert set(co) >= {"mode", "selftest", "schedule", "rccl_communicator", "two_stream_rows", "fallbacks", "allreduce_us"}
+    assert set(co["allreduce_us"]) >= {"rows", "bytes", "chosen_path", "rccl"}
+    assert "schedule" in res and res["ms_per_step_ranks"]["min"] <= res["ms_per_step_ranks"]["max"]
+    # rank r sleeps (r + 1) ms per step: min = the fastest rank's own time (before the closing barrier), max = the headline time
+    assert 0.9 <= res["ms_per_step_ranks"]["min"] < 1.9 <= res["ms_per_step_ranks"]["max"] and abs(res["ms_per_step"] - res["ms_per_step_ranks"]["max"]) < 1e-3
 
 
 def test_bench_self_launches_without_a_launcher():
