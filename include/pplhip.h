@@ -206,6 +206,12 @@ PPLHIP_API int pplhip_rank_set_tensor(pplhip_ctx* ctx, int rank, const char* nam
  * oracle/llama_ref.c restates (synthetic weights for benchmarks and parity tests). */
 PPLHIP_API int pplhip_rank_init_synthetic(pplhip_ctx* ctx, int rank, uint64_t seed);
 
+/* a synthetic model whose greedy answers have a wide top-2 margin (token t is followed by t + shift): the embedding table regenerated
+ * from `seed` at amplitude embed_amp (0: kept) and output.weight[v] := tok_embeddings.weight[(v - shift) mod vocab] on this rank's shard.
+ * For harness checks that compare the answers of two runs token for token (tools/benchmark_prefix_cache_offline
+ * --synthetic-decisive-head; the reference compares nothing: benchmark_prefix_cache_offline.cc:442-508). */
+PPLHIP_API int pplhip_rank_tie_output(pplhip_ctx* ctx, int rank, int64_t shift, uint64_t seed, float embed_amp);
+
 /* ================================================================================================
  * KV cache slab -- replaces the cudaMemGetInfo/cudaMalloc block of InitTask
  *                  (src/backends/cuda/resource_manager.cc:329-362)

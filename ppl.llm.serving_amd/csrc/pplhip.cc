@@ -627,6 +627,9 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
         c->dual_auto = tp > 1 && !getenv("PPLHIP_EMULATE_TP");
         c->dual_mode = c->dual_auto ? 1 : 0;
         if (c->dual_auto) { c->dual_min_rows = 512; c->dual_max_rows = 1024; }
+        // (no second stream, communicator or workspace for a context whose steps can never reach the window: a whole tp-8 group on ONE
+        // device -- the tests -- already needs 16 hardware queues for its compute and communication streams)
+        if (c->dual_auto && opts->max_running_batch < c->dual_min_rows) { c->dual_auto = false; c->dual_mode = 0; }
     }
     if (const char* e = getenv("PPLHIP_DUAL_MIN_ROWS")) c->dual_min_rows = std::max(2, atoi(e));
     if (const char* e = getenv("PPLHIP_DUAL_MAX_ROWS")) c->dual_max_rows = atoi(e);
@@ -1013,6 +1016,31 @@ int pplhip_rank_init_synthetic(pplhip_ctx* c, int rank, uint64_t seed) {
 }
 
 /* ------------------------------------------------------------------------------------------------ KV slab */
+
+// A DECISIVE synthetic model: the embedding table is regenerated at amplitude `embed_amp` (the synthetic default is 1; behind 32 synthetic
+// layers the residual stream has an rms of ~10, which buries a unit-amplitude embedding: profiles/r05_tie_probe.log) and
+// output.weight[v] := tok_embeddings.weight[(v - shift) mod vocab] on this rank's vocabulary shard.  The final hidden state of a position
+// then keeps a strong component along its own token's embedding, so token t is answered by t + shift with a top-2 margin of a third or more of the
+// logit scale -- far above what two evaluation orders of the same arithmetic differ by.  For harness checks that compare ANSWERS of two
+// runs (benchmark_prefix_cache_offline --synthetic-decisive-head: cold run vs prefix-cache hits); what such a check pins is the
+// bookkeeping of the path (pages, start positions, hand-over of tokens), not its arithmetic.
+int pplhip_rank_tie_output(pplhip_ctx* c, int rank, int64_t shift, uint64_t seed, float embed_amp) {
+    if (!c || rank < 0 || rank >= (int)c->ranks.size()) return PPLHIP_INVALID_VALUE;
+    Rank& R = c->ranks[rank];
+    if (R.output.qbit != 0) return fail(c, rank, PPLHIP_INVALID_VALUE, "tie_output: the lm_head is fp16");
+    HIPCK(c, rank, hipSetDevice(R.device));
+    const int64_t V = c->d.vocab_size, hd = c->d.hidden_dim, v0 = (int64_t)R.global_rank * c->vocab_local;
+    if (embed_amp > 0.f) HIPCK(c, rank, launch_synth_fill(R.stream, 0, seed, (uint32_t)(0 * 32 + 0), 0, embed_amp, (uint64_t)V * hd, R.embed));   // tensor id of pplhip_rank_init_synthetic's embedding
+    shift = ((shift % V) + V) % V;
+    for (int64_t v = 0; v < c->vocab_local;) {          // at most two contiguous runs
+        const int64_t src = ((v0 + v - shift) % V + V) % V;
+        const int64_t n = std::min<int64_t>(c->vocab_local - v, V - src);
+        HIPCK(c, rank, hipMemcpyAsync((char*)R.output.w + v * hd * 2, (const char*)R.embed + src * hd * 2, (size_t)n * hd * 2, hipMemcpyDeviceToDevice, R.stream));
+        v += n;
+    }
+    HIPCK(c, rank, hipStreamSynchronize(R.stream));
+    return 0;
+}
 
 int pplhip_kv_block_bytes(pplhip_ctx* c, uint64_t* cache_bytes, uint64_t* scale_bytes) {
     if (!c) return PPLHIP_INVALID_VALUE;

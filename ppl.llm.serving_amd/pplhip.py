@@ -82,7 +82,7 @@ class CommInfo(C.Structure):
 SYMBOLS = [
     "pplhip_version", "pplhip_device_count", "pplhip_get_unique_id", "pplhip_init", "pplhip_destroy",
     "pplhip_comm_export", "pplhip_comm_connect", "pplhip_comm_mode", "pplhip_comm_info", "pplhip_comm_allreduce_us",
-    "pplhip_last_error", "pplhip_rank_load", "pplhip_rank_set_tensor", "pplhip_rank_init_synthetic",
+    "pplhip_last_error", "pplhip_rank_load", "pplhip_rank_set_tensor", "pplhip_rank_init_synthetic", "pplhip_rank_tie_output",
     "pplhip_kv_block_bytes", "pplhip_kv_capacity", "pplhip_kv_alloc", "pplhip_kv_ptrs", "pplhip_kv_read",
     "pplhip_kv_write", "pplhip_kv_fill_synthetic", "pplhip_set_inputs", "pplhip_run", "pplhip_debug_run_dump", "pplhip_logits", "pplhip_copy_logits", "pplhip_sync",
     "pplhip_sample", "pplhip_penalty", "pplhip_profile_reset", "pplhip_profile_get", "pplhip_profile_mode", "pplhip_mem_info",
@@ -117,6 +117,7 @@ def lib():
         L.pplhip_rank_load.argtypes = [vp, C.c_int, C.c_char_p]
         L.pplhip_rank_set_tensor.argtypes = [vp, C.c_int, C.c_char_p, vp, u64]
         L.pplhip_rank_init_synthetic.argtypes = [vp, C.c_int, u64]
+        L.pplhip_rank_tie_output.argtypes = [vp, C.c_int, i64, u64, f32]
         L.pplhip_kv_block_bytes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
         L.pplhip_kv_capacity.argtypes = [vp, f32, C.POINTER(u64)]
         L.pplhip_kv_alloc.argtypes = [vp, C.c_int, u64]

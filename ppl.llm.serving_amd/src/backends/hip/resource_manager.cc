@@ -100,6 +100,7 @@ static RetCode InitRank(uint32_t id, pplhip_ctx* ctx, const ResourceConfig& rc, 
     int st;
     if (rc.synthetic_weights) {
         st = pplhip_rank_init_synthetic(ctx, (int)id, rc.synthetic_seed);
+        if (!st && rc.synthetic_decisive_head) st = pplhip_rank_tie_output(ctx, (int)id, rc.synthetic_decisive_head, rc.synthetic_seed, 4.0f);   // margins 0.35-0.68 of the logit scale at 32 layers (profiles/r05_tie_probe.log)
     } else {
         const std::string slice = rc.model_dir + "/model_slice_" + std::to_string(id);
         LOG(INFO) << "model_slice_" << id << ": " << slice;

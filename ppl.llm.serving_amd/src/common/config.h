@@ -26,6 +26,7 @@ struct ResourceConfig final {
     // ---- hip backend only ------------------------------------------------------------------------------------------
     bool synthetic_weights = false;              // --synthetic-weights: device-side generator instead of loading slices
     uint64_t synthetic_seed = 1234;              // --synthetic-seed
+    int64_t synthetic_decisive_head = 0;         // --synthetic-decisive-head N: lm_head row v = embedding row v - N (pplhip_rank_tie_output); 0: off
     uint64_t kv_cache_max_tokens_override = 0;   // --kv-cache-max-tokens: > 0 pins the slab size (tests, benchmarks)
     // ---- engine options of the reference's command line; the hip backend honours the last three -------------------
     struct EngineConfig {

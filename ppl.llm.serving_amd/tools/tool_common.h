@@ -57,6 +57,7 @@ inline void DefineCommonFlags(Args* a) {
     // additions of this build
     a->Def("--synthetic-weights", "false", "fill the model slices with the synthetic generator instead of loading", true);
     a->Def("--synthetic-seed", "1234", "");
+    a->Def("--synthetic-decisive-head", "0", "with --synthetic-weights: lm_head row v = embedding row v - N, i.e. token t is answered by t + N with a wide margin (answers of two runs can then be compared token for token); 0: off");
     a->Def("--kv-cache-max-tokens", "0", "pin the KV slab size in tokens (0: max-tokens-scale x free memory)");
     a->Def("--seed", "1234", "workload seed");
 }
@@ -73,6 +74,7 @@ inline bool FillConfigs(const Args& a, ppl::llm::ResourceConfig* rc, ppl::llm::G
     rc->enable_penalty = a.Bool("--enable-penalty");
     rc->synthetic_weights = a.Bool("--synthetic-weights");
     rc->synthetic_seed = (uint64_t)a.I64("--synthetic-seed");
+    rc->synthetic_decisive_head = a.I64("--synthetic-decisive-head");
     rc->kv_cache_max_tokens_override = (uint64_t)a.I64("--kv-cache-max-tokens");
     rc->engine_config.cublas_layout_hint = a.Str("--cublas-layout-hint");
     rc->engine_config.disable_graph_fusion = a.Bool("--disable-graph-fusion");

@@ -205,9 +205,29 @@ def test_config5_cache_prefill_2048_behind_6144_cached_tokens_vs_oracle():
         rel = max(1e-3, 2.5 * noise)                                        # the bar of tests/test_gpu_model.py (NOISE_RATIO)
         record_err("config5_cache_prefill_2048_behind_6144_logits", err, min(rel, 4e-3), noise=noise)
         assert err <= min(rel, 4e-3), (err, noise)
-        srt = np.sort(want[0])
-        if srt[-1] - srt[-2] > 2 * rel * scale:                             # greedy token of the answer
-            assert got[0].argmax() == want[0].argmax()
+        # greedy token of the answer, UNCONDITIONALLY (with synthetic weights the top-2 margin seldom clears the bar and the
+        # assertion was vacuous): the lm_head row of a chosen token is engineered from the ORACLE's final hidden state of the answer row
+        # (tests/test_gpu_fulldepth.py's construction) to sit a quarter of the logit scale above every other token; the step is then run
+        # again on both sides -- it rewrites the same K / V bytes, so the caches stay what they were -- and both must answer the chosen token
+        _, dump = ref.forward([rm], rm_st, dump_hidden=True)
+        hfin = dump[-1][-1].astype(np.float64)                               # residual stream of the last token behind the last layer
+        wn = rm.get_tensor("norm.weight", np.float16).astype(np.float64)
+        y = hfin / np.sqrt((hfin * hfin).mean() + float(desc.norm_eps)) * wn
+        chosen_tok = 1234
+        head = rm.get_tensor("output.weight", np.float16).reshape(desc.vocab_size, -1).copy()
+        oth = head.astype(np.float64) @ y
+        oth[chosen_tok] = -np.inf
+        head[chosen_tok] = ((oth.max() + 0.25 * scale) * y / (y @ y)).astype(np.float16)
+        rm.set_tensor("output.weight", head)
+        ctx.set_tensor(0, "output.weight", head)
+        want2 = ref.forward([rm], rm_st)
+        ctx.set_inputs(0, dv_st)
+        ctx.run(0, cache_prefill=1)
+        got2 = ctx.copy_logits(1)
+        srt = np.sort(want2[0])
+        assert srt[-1] - srt[-2] > 8 * rel * scale                          # the engineered margin is there ...
+        assert want2[0].argmax() == chosen_tok and got2[0].argmax() == chosen_tok   # ... and both sides answer the chosen token
+        assert float(np.abs(got2 - want2).max()) / max(1.0, float(np.abs(want2).max())) <= min(rel, 4e-3)
         # the int8 K / V bytes and scales the step appended (and everything it must not have touched): a few LSB on few bytes
         gk, rk = ctx.kv_read(0, 0), rm.kv_array(0)
         assert (np.abs(gk.astype(np.int32) - rk.astype(np.int32)) <= 3).all()

@@ -209,3 +209,26 @@ def test_prefix_cache_benchmark_config5_shape_7b(tmp_path):
     cold, cached = lines[:3], lines[3:]
     agree = [next((i for i in range(6) if a[i] != b[i]), 6) for a, b in zip(cold, cached)]   # tokens in common before the first difference
     assert sum(agree) >= 9 and min(agree) >= 1, (agree, cold, cached)
+
+
+def test_prefix_cache_benchmark_answers_identical_with_a_decisive_head(tmp_path):
+    """the same harness with a DECISIVE synthetic model (--synthetic-decisive-head 7: lm_head row v = embedding row v - 7, so every token t
+    is answered by t + 7 with a top-2 margin of a third of the logit scale; pplhip_rank_tie_output): the cached run -- prefix-cache hits,
+    cache-prefill of the last page, its own decode steps -- must answer EVERY request exactly like the cold run (VERDICT r4 item 5:
+    `identical_answers` == batch; with the plain synthetic head 51 of 64 did, the rest being near-ties).  What this pins is the hit path's
+    bookkeeping (pages, start positions, token hand-over); its arithmetic is pinned in tests/test_gpu_config5_tokens.py and
+    tests/test_gpu_config34_shape.py."""
+    dump = tmp_path / "answers.txt"
+    cfg = os.path.join(PKG, "configs", "llama2_7b_w8a16_kv8_paged.json")
+    out = subprocess.check_output([tool("benchmark_prefix_cache_offline"), "--model-param-path", cfg, "--synthetic-weights",
+                                   "--synthetic-decisive-head", "7", "--enable-prefix-cache", "--max-prefill-batch", "1",
+                                   "--max-input-tokens-per-request", "8192", "--max-total-tokens-per-request", "16384",
+                                   "--kv-cache-max-tokens", "98304", "--batch", "8", "--generation-length", "12", "--dump-answers", str(dump)],
+                                  timeout=900).decode()
+    res = json.loads(out.strip().splitlines()[-1])
+    assert res["batch"] == 8 and res["identical_answers"] == 8, res
+    lines = [[int(x) for x in l.split()] for l in open(dump).read().splitlines()]
+    assert len(lines) == 16 and lines[:8] == lines[8:]
+    # the model is the decisive one: every answer continues its prompt's last token in steps of 7 (mod vocab)
+    for l in lines[:8]:
+        assert all((b - a) % 32000 == 7 for a, b in zip(l, l[1:])), l
