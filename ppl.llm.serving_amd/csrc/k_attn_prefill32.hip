@@ -22,13 +22,11 @@ namespace pplhip {
 namespace {
 
 constexpr int P3_BN = 64, P3_D = 128;
-// P3_P_EXACT 1 (default): P enters P . V as an exact hi + lo pair of fp16 numbers (two MFMAs per block).  0: P rounded to nearest fp16 once --
-// measured in round 4 (profiles/r03_prefill_attention_ablation.md): 8192-token prompt 1002 -> 820 us (670 TFLOP/s counted), 4 x 2048 323 ->
-// 227 us, 2048 behind 6144 cached 482 -> 369 us; every test still passes, but the operator's largest error against the oracle goes from
-// 1.6e-4 / 2.6e-4 to 6.5e-4 of max|out| (tolerance 1e-3) -- two thirds of the tolerance for 1 % of a prefill step: kept as a build switch
-#ifndef P3_P_EXACT
-#define P3_P_EXACT 1
-#endif
+// P enters P . V as an exact hi + lo pair of fp16 numbers (two MFMAs per block): DECIDED in round 5, the build switch of rounds 3-4 is gone.
+// P rounded to nearest once measured 8192-token prompt 1002 -> 820 us (549 -> 670 TFLOP/s counted) with every test green, but it raises the
+// MODEL-level distance to the oracle where the margin is thinnest -- 32-layer 7B logits 1.14e-2 -> 1.35e-2 (1.03 -> 1.22 x the noise floor,
+// bar 1.3), config 5's cache-prefill step 1.05e-3 -> 1.17e-3 (1.5 x its floor); profiles/r05_parity_prefill_p_{exact,rounded}.jsonl -- the same
+// trade that the grouped-query decode kernel's rounded V turned out to be (k_attn_decode_gqa.hip).  Precision first: ~5 % of a cold TTFT.
 constexpr int P3_VSUB = 272;  // halfs per [16 keys][16 channels] V sub-tile: 256 + 16 of skew
 constexpr int P3_KS_HALFS = P3_BN * P3_D, P3_VS_HALFS = (P3_BN / 16) * (P3_D / 16) * P3_VSUB;
 typedef float f16v __attribute__((ext_vector_type(16)));
@@ -289,13 +287,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     for (int c = 0; c < 4; ++c) o[c][i] *= ar;
                 }
             }
-            // ---- O += P . V over four 16-key k-steps.  P3_P_EXACT 1: P as an exact hi + lo pair (mask, subtract, v_cvt_pkrtz: two MFMAs per
-            // block); 0: P rounded to NEAREST fp16 once (unbiased, relative error <= 2^-12; one MFMA) --------------------------------------
+            // ---- O += P . V over four 16-key k-steps; P as an exact hi + lo pair (mask, subtract, v_cvt_pkrtz: two MFMAs per block) -----------
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 typedef __fp16 pk_h2 __attribute__((ext_vector_type(2)));
                 h8 pa, pl;
-                if constexpr (P3_P_EXACT) {
+                {
                     uint32_t hw[4], lw[4];
 #pragma unroll
                     for (int q2 = 0; q2 < 4; ++q2) {
@@ -306,16 +303,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     }
                     pa = __builtin_bit_cast(h8, make_uint4(hw[0], hw[1], hw[2], hw[3]));
                     pl = __builtin_bit_cast(h8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) pa[q] = (_Float16)sacc[s >> 1][8 * (s & 1) + q];
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const uint16_t* sub = Vs + (s * (D / 16) + 2 * c + chblk) * P3_VSUB;  // keys 16 s .. + 16, channels 32 c + 16 chblk .. + 16
                     const uint2 v0 = p3_v_frag(sub, 4 * hi, l15), v1 = p3_v_frag(sub, 8 + 4 * hi, l15);
                     const h8 bv = __builtin_bit_cast(h8, make_uint4(v0.x, v0.y, v1.x, v1.y));
-                    if constexpr (P3_P_EXACT) { if (!(ABL & 1)) o[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, bv, o[c], 0, 0, 0); }
+                    if (!(ABL & 1)) o[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, bv, o[c], 0, 0, 0);
                     o[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa, bv, o[c], 0, 0, 0);
                 }
             }
