@@ -78,6 +78,12 @@ __device__ __forceinline__ uint32_t lds_ld4(uint32_t a) {
 #define PC_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 #endif
 #define PC_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#ifdef PC_TIME_BUILD   // diagnosis build (profiles/probes/w4_pc_timeline.sh): cycle stamps of every wave of block 0 at the protocol's points
+__device__ uint64_t pc_time_log[8][256];
+#define PC_T() do { if (blockIdx.x == 0 && lane == 0 && ti < 256) pc_time_log[wave][ti] = __builtin_readcyclecounter(); ++ti; } while (0)
+#else
+#define PC_T() do {} while (0)
+#endif
 
 // EPI: EPI_F16 / EPI_SWIGLU
 template <int EPI>
@@ -106,6 +112,9 @@ __global__ __launch_bounds__(512) void gemm_w4_pc_kernel(const uint16_t* __restr
     const int nst = G;                                 // >= 1 (launcher)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int ti = 0;
+    (void)ti;
+    PC_T();                                            // 0: start
 
     // Barrier B_j (j = 0 .. nst) "super-tile j is published": the producers have seen the activations of super-tile j and the raw
     // weights + scales of super-tile j + 1 land; the consumers have every fragment of super-tile j - 1 in registers (so the slots of
@@ -153,16 +162,21 @@ __global__ __launch_bounds__(512) void gemm_w4_pc_kernel(const uint16_t* __restr
         // prologue: R S X(0) | R S X(1) | R S X(2) | R S (3); iteration j then issues R S (j + 4), X(j + 3)
         issue_r(0); issue_x(0); issue_r(1); issue_x(1); issue_r(2); issue_x(2); issue_r(3);
         PC_VMCNT(2 + 10);                              // x(0) [and raw(0), raw(1)] landed: younger = raw(3) (2) + all of super-tile 2 (10)
+        PC_T();                                        // 1: prologue loads landed
         __builtin_amdgcn_s_barrier();                  // B_0
         __builtin_amdgcn_s_barrier();                  // B_0': the consumers hold super-tile 0 and raw(1) in registers (raw slot 0 is free)
+        PC_T();                                        // 2: behind B_0'
         for (int j = 0; j < nst; ++j) {
             // behind B_j: raw slot j % 4 and activation slot (j - 1) % 4 are free
             issue_r(j + PC_NS);
             issue_x(j + PC_NS - 1);
+            PC_T();                                    // 3 + 3 j: issued
             // x(j + 1) and raw(j + 2) landed.  x(j + 1) was issued two iterations ago (in the prologue for j < 2); younger than its last
             // piece: j = 0: R S of super-tile 3 (2) + x(2)'s group (8) + this iteration (10) = 20 -- and 20 in the steady state as well
             if (j + 1 < nst) PC_VMCNT(20); else PC_VMCNT(0);   // last iteration: everything (the epilogue reuses the rings)
+            PC_T();                                    // 4 + 3 j: landed
             __builtin_amdgcn_s_barrier();              // B_{j+1}
+            PC_T();                                    // 5 + 3 j: behind the barrier
         }
         __builtin_amdgcn_s_barrier();                  // (the consumers' barrier inside the exchange of their k halves)
     } else {
@@ -213,6 +227,7 @@ __global__ __launch_bounds__(512) void gemm_w4_pc_kernel(const uint16_t* __restr
 
         // prologue: everything of super-tile 0, the raw weights of super-tile 1
         __builtin_amdgcn_s_barrier();                  // B_0
+        PC_T();                                        // 1: behind B_0
         PC_RAW_READ(0);
         {
             const h2 sc2 = scale_of(g0);
@@ -227,13 +242,17 @@ __global__ __launch_bounds__(512) void gemm_w4_pc_kernel(const uint16_t* __restr
         PC_RAW_READ(1);
         PC_LGKM0();
         __builtin_amdgcn_s_barrier();                  // B_0'
+        PC_T();                                        // 2: behind B_0'
 
         // phase of super-tile s (slot p = s % 4): MFMAs of s; behind k-step ks its registers take k-step ks of super-tile s + 1 (slot p + 1);
         // the raw weights of s + 2 (slot p + 2) are read at the end
 #define PC_PHASE(P)                                                                                                       \
     do {                                                                                                                  \
+        PC_T();                                        /* 3 + 3 s: phase top */                                           \
         PC_LGKM0();                                    /* every read of super-tile s + 1's predecessors has landed */     \
+        PC_T();                                        /* 4 + 3 s: reads landed */                                        \
         __builtin_amdgcn_s_barrier();                  /* B_{s+1} */                                                      \
+        PC_T();                                        /* 5 + 3 s: behind the barrier */                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                                \
         const h2 sc2 = scale_of(g0 + s0 + (P) + 1);                                                                       \
         const uint32_t wv[4] = {rw.x, rw.y, rw.z, rw.w};                                                                  \
@@ -268,6 +287,7 @@ __global__ __launch_bounds__(512) void gemm_w4_pc_kernel(const uint16_t* __restr
 #undef PC_XADDR
         // ---- epilogue, part 1: the k halves are added through LDS (the rings are idle: every DMA has landed, every fragment is read),
         // then accumulators -> LDS staging image.  accumulator j, value e of lane (r, hh): channel 32 wn + 8 (e >> 2) + 4 hh + (e & 3), row 32 j + r
+        PC_T();                                        // loop done
         PC_LGKM0();                                    // (the last phase's look-ahead reads)
         {
             float4* const red = reinterpret_cast<float4*>(smem_pc + 64 * 1024);   // [wn][j][g][lane] float4: 32 KiB behind the staging image
@@ -317,7 +337,9 @@ __global__ __launch_bounds__(512) void gemm_w4_pc_kernel(const uint16_t* __restr
         }
     }
     // ---- epilogue, part 2 (all eight waves): whole rows of the staging image -> global memory, 16 bytes per lane
+    PC_T();                                            // staged
     __syncthreads();
+    PC_T();
     {
         constexpr int OUTW = EPI == EPI_SWIGLU ? PC_BN / 2 : PC_BN, PITCH = OUTW * 2 + 16, CPR = OUTW / 8;
         uint16_t* const y = reinterpret_cast<uint16_t*>(yv);
@@ -339,6 +361,7 @@ __global__ __launch_bounds__(512) void gemm_w4_pc_kernel(const uint16_t* __restr
             }
         }
     }
+    PC_T();                                            // stores issued
 }
 
 }  // namespace
@@ -377,6 +400,23 @@ hipError_t launch_linear_w4_pc(hipStream_t s, const uint16_t* x, const void* w, 
         hipLaunchKernelGGL((gemm_w4_pc_kernel<EPI_SWIGLU>), grid, block, PC_LDS, s, x, wq, scale, M, N, K, y, ldy, n_tiles, m_tiles, abl);
     else
         hipLaunchKernelGGL((gemm_w4_pc_kernel<EPI_F16>), grid, block, PC_LDS, s, x, wq, scale, M, N, K, y, ldy, n_tiles, m_tiles, abl);
+#ifdef PC_TIME_BUILD
+    if (getenv("PPLHIP_PC_TIME")) {
+        static int calls = 0;
+        if (++calls == 5) {   // a warm call
+            (void)hipStreamSynchronize(s);
+            static uint64_t h[8][256];
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(pc_time_log), sizeof(h));
+            const int nst = K / 128;
+            for (int w = 0; w < 8; ++w) {
+                fprintf(stderr, "[pc_time] wave %d (%s) N=%d K=%d:", w, w < 4 ? "consumer" : "producer", N, K);
+                const int n = 3 + 3 * nst + 4;
+                for (int i = 1; i < n && i < 256; ++i) fprintf(stderr, " %lld", (long long)(h[w][i] - h[w][0]));
+                fprintf(stderr, "\n");
+            }
+        }
+    }
+#endif
     return hipGetLastError();
 }
 

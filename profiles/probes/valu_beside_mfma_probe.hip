@@ -76,9 +76,11 @@ double run(uint32_t* out, uint64_t* cyc, int iters) {
 }
 
 #define ROW(T) run<T, 0, 1>(out, cyc, it); run<T, 4, 1>(out, cyc, it); run<T, 6, 1>(out, cyc, it); run<T, 8, 1>(out, cyc, it); run<T, 10, 1>(out, cyc, it); run<T, 12, 1>(out, cyc, it); run<T, 10, 0>(out, cyc, it);
-int main() {
+int main2(uint32_t* out, uint64_t* cyc);
+int main(int argc, char** argv) {
     uint32_t* out; uint64_t* cyc;
-    hipMalloc(&out, 256 * 256 * 4); hipMalloc(&cyc, 256 * 8);
+    hipMalloc(&out, 256 * 1024 * 4); hipMalloc(&cyc, 256 * 8);
+    if (argc > 1) return main2(out, cyc);
     const int it = 20000;
     const char* names[] = {"v_and_b32", "v_perm_b32", "v_pk_mul_f16", "v_pk_add_f16", "v_fma_mixlo_f16", "v_fma_f32", "v_and_or_b32", "v_pk_fma_f16",
                            "v_lshrrev_b32", "v_mul_f16", "v_cvt_f16_f32", "v_cvt_pkrtz_f16_f32", "v_mul_f32", "v_cvt_f32_ubyte0", "v_bfe_u32"};
@@ -97,5 +99,67 @@ int main() {
     printf("%s\n", names[12]); ROW(12)
     printf("%s\n", names[13]); ROW(13)
     printf("%s\n", names[14]); ROW(14)
+    return 0;
+}
+
+// ---- second question: TWO waves per SIMD with different roles.  Waves 0..3 issue only MFMAs (8 per iteration), waves 4..NW-1 only fillers
+// (96 per iteration): do the two streams overlap on a SIMD (time = max) or add up?  cyc[0] = an MFMA wave's cycles, cyc[1] = a filler wave's.
+template <int T, int NW>
+__global__ __launch_bounds__(NW * 64) void roles(uint32_t* out, uint64_t* cyc, int iters) {
+    const int wave = threadIdx.x >> 6;
+    h8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x * 0.001f + i); b[i] = (_Float16)(0.5f - i * 0.01f); }
+    f16v acc0, acc1;
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    uint32_t r[16];
+    for (int i = 0; i < 16; ++i) r[i] = threadIdx.x * 7 + i;
+    uint32_t s0 = 0x3c003c00u + threadIdx.x, s1 = 0x0f0f0f0fu;
+    float fs = 1.5f;
+    uint64_t t0 = __builtin_readcyclecounter();
+    if (wave < 4) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc1, 0, 0, 0);
+            }
+        }
+    } else {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 96; ++i) filler<T>(r[i & 15], s0, s1, fs);
+        }
+    }
+    uint64_t t1 = __builtin_readcyclecounter();
+    uint32_t x = 0;
+    for (int i = 0; i < 16; ++i) x ^= r[i];
+    float sacc = 0;
+    for (int i = 0; i < 16; ++i) sacc += acc0[i] + acc1[i];
+    out[blockIdx.x * NW * 64 + threadIdx.x] = x ^ __float_as_uint(sacc);
+    if (threadIdx.x == 0) cyc[0] = t1 - t0;
+    if (threadIdx.x == 256) cyc[1] = t1 - t0;
+    if (threadIdx.x == 512) cyc[2] = t1 - t0;
+}
+template <int T, int NW>
+void run_roles(uint32_t* out, uint64_t* cyc, int iters) {
+    hipMemset(cyc, 0, 64);
+    hipLaunchKernelGGL((roles<T, NW>), dim3(256), dim3(NW * 64), 0, 0, out, cyc, 64);
+    hipDeviceSynchronize();
+    hipLaunchKernelGGL((roles<T, NW>), dim3(256), dim3(NW * 64), 0, 0, out, cyc, iters);
+    hipDeviceSynchronize();
+    uint64_t c[3];
+    hipMemcpy(c, cyc, 24, hipMemcpyDeviceToHost);
+    printf("roles T=%2d waves/SIMD %d: MFMA wave %7.1f cycles / iter (8 MFMAs), filler wave %7.1f (96 fillers), second filler wave %7.1f\n", T, NW / 4,
+           (double)c[0] / iters, (double)c[1] / iters, (double)c[2] / iters);
+}
+int main2(uint32_t* out, uint64_t* cyc) {
+    const int it = 20000;
+    run_roles<2, 4>(out, cyc, it);    // MFMA waves alone
+    run_roles<2, 8>(out, cyc, it);    // + one v_pk_mul_f16 wave per SIMD
+    run_roles<2, 12>(out, cyc, it);   // + two
+    run_roles<1, 8>(out, cyc, it);    // v_perm_b32
+    run_roles<1, 12>(out, cyc, it);
+    run_roles<5, 8>(out, cyc, it);    // v_fma_f32
+    run_roles<5, 12>(out, cyc, it);
     return 0;
 }
