@@ -8,6 +8,8 @@ from tests.conftest import load_pplhip
 m = load_pplhip()
 WQ = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 shapes = [("wqkv", 12288, 4096), ("wo", 4096, 4096), ("w13", 22016, 4096), ("w2", 4096, 11008)]
+if os.environ.get("SHAPES"):   # e.g. SHAPES=w13,wo
+    shapes = [s for s in shapes if s[0] in os.environ["SHAPES"].split(",")]
 MS = [int(a) for a in sys.argv[2:]] or [1, 2, 3, 4, 8]
 for M in MS:
     tot_t = tot_b = 0
