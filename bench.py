@@ -179,7 +179,7 @@ def serving_leg(model_kw, args):
             "max_running": r["max_running"], "process_wall_s": round(wall, 1), "paced": paced}
 
 
-def dry_run(args, P, dist, rank, world):
+def dry_run(args, P, dist, rank, world, guard=None):
     """the N>1 control plane without a GPU: rendezvous, unique-id broadcast, barrier-bracketed timing, MAX over ranks,
     one JSON line from rank 0.  (tests/test_tp_gloo.py)"""
     uid = None
@@ -190,13 +190,21 @@ def dry_run(args, P, dist, rank, world):
             uid = os.urandom(P.UNIQUE_ID_BYTES)
     agreed = True
     if dist is not None:
+        if guard is not None:
+            guard.at("RCCL unique-id broadcast")
         box = [uid]
         dist.broadcast_object_list(box, src=0)
         uid = box[0]
+        if args.dry_run_fail_rank == rank:   # test hook: a rank that dies before the handle exchange (tests/test_tp_gloo.py)
+            os._exit(17)
+        if guard is not None:
+            guard.at("IPC-handle exchange")
         allv = [None] * world
         dist.all_gather_object(allv, uid)
         agreed = all(v == allv[0] for v in allv) and len(uid) == P.UNIQUE_ID_BYTES
         dist.barrier()
+    if guard is not None:
+        guard.disarm()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(0.001 * (rank + 1))
@@ -246,6 +254,56 @@ def emit(obj):
     _JSON_OUT.flush()
 
 
+
+class StartupGuard:
+    """Wall-clock guard around a multi-process start-up (rendezvous, library init, IPC-handle exchange, collective self-test, warm-up).
+    A rank that never reaches the rendezvous, a peer that died, an RCCL bootstrap that waits for ever: without this the driver's
+    `bench.py --gpus N` hangs until ITS limit and leaves nothing to read.  With it rank 0 prints the contract's ONE JSON line carrying
+    "error" (what was being waited for, after how long) and whatever the collectives had reported so far ("collectives.fallbacks"),
+    and every rank exits non-zero.  Fired by a timer thread (the main thread may sit in a blocking C call), by SIGTERM (the launcher
+    tearing the group down because a peer failed) and by an exception on the way.  Disarmed when the timed region starts."""
+
+    def __init__(self, args, rank, world, timeout_s):
+        import threading
+        self.args, self.rank, self.world, self.timeout_s = args, rank, world, timeout_s
+        self.phase, self.t0, self.info, self.done = "start", time.perf_counter(), None, False
+        self.lock = threading.Lock()
+        self.timer = None
+        if world > 1 and timeout_s > 0:
+            self.timer = threading.Timer(timeout_s, self.fire, args=(f"start-up guard: no progress past '{{phase}}' within {timeout_s:.0f} s",))
+            self.timer.daemon = True
+            self.timer.start()
+            import signal
+            signal.signal(signal.SIGTERM, lambda *_: self.fire("terminated by the launcher during '{phase}' (a peer rank failed?)", code=143))
+
+    def at(self, phase):
+        self.phase = phase
+
+    def disarm(self):
+        self.done = True
+        if self.timer is not None:
+            self.timer.cancel()
+
+    def fire(self, why, code=3):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+        msg = why.replace("{phase}", self.phase)
+        print(f"[bench] rank {self.rank}: {msg} (after {time.perf_counter() - self.t0:.1f} s)", file=sys.stderr, flush=True)
+        if self.rank == 0:
+            co = self.info if isinstance(self.info, dict) else {"mode": "unknown (start-up did not get that far)", "fallbacks": ""}
+            try:
+                emit({"metric": "decode tokens/sec, LLaMA-7B int8 (W8A16), max-running-batch 1024", "value": 0.0, "unit": "tokens/s",
+                      "n_gpus": self.world, "steps": self.args.steps, "warmup": self.args.warmup, "ms_per_step": None,
+                      "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "error": msg, "phase": self.phase,
+                      "elapsed_s": round(time.perf_counter() - self.t0, 1), "collectives": co,
+                      "config": {"workload": "not run (start-up failed)", "parallelism": f"tp{self.world}"}})
+            except Exception:
+                pass
+        os._exit(code)
+
+
 def self_launch(n):
     """`python bench.py --gpus N` outside a launcher: become `python -m torch.distributed.run ... bench.py --gpus N ...`
     (one process per GPU, the same command line the driver uses).  stdout stays the rank-0 JSON line."""
@@ -290,6 +348,9 @@ def main():
     ap.add_argument("--emulate-tp", type=int, default=0,
                     help="profiling only: run ONE rank's slice of a tp-way step on one GPU (collectives are local "
                          "identities, logits incomplete); the printed line is marked invalid as a throughput number")
+    ap.add_argument("--startup-timeout", type=float, default=float(os.environ.get("PPLHIP_BENCH_STARTUP_TIMEOUT", "900")),
+                    help="N > 1: seconds the start-up (rendezvous .. end of warm-up) may take before rank 0 prints the JSON line with \"error\" and every rank exits non-zero (0: no guard)")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help="test hook (--dry-run): this rank exits before the handle exchange")
     ap.add_argument("--dry-run", action="store_true",
                     help="no device work: exercises only the multi-process control plane (CPU test of the N>1 path)")
     args = ap.parse_args()
@@ -302,6 +363,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         args.gpus = world
+    guard = StartupGuard(args, rank, world, args.startup_timeout)
+    try:
+        return run(args, guard, world, rank, local_rank)
+    except SystemExit:
+        raise
+    except BaseException as e:   # (a peer that vanished shows up here as a gloo / library error on the survivors)
+        if world > 1:
+            guard.fire(f"{type(e).__name__} during '{{phase}}': {str(e)[:300]}", code=1)
+        raise
+
+
+def run(args, guard, world, rank, local_rank):
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
@@ -312,11 +385,15 @@ def main():
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL P2P setup)
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        import datetime
+        guard.at("rendezvous (torch.distributed, gloo)")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=max(30.0, args.startup_timeout or 1800.0)))
 
+    guard.at("loading libpplhip")
     P = load_pplhip()
     if args.dry_run:
-        return dry_run(args, P, dist, rank, world)
+        return dry_run(args, P, dist, rank, world, guard)
     mk = dict(MODELS[args.model])
     if args.layers:
         mk["num_layers"] = args.layers
@@ -328,6 +405,7 @@ def main():
                        weight_quant_bit=args.weight_quant, act_quant_bit=args.act_quant, **mk)
     uid = None
     p2p_only = os.environ.get("PPLHIP_COMM") == "p2p"
+    guard.at("RCCL unique-id broadcast")
     if world > 1 and not p2p_only:
         box = [P.get_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
@@ -340,12 +418,14 @@ def main():
     # PPLHIP_BENCH_ONE_DEVICE=1 (tests): every rank on device 0 -- the multi-process plumbing (IPC handles, direct
     # collectives) on a one-GPU box; needs PPLHIP_COMM=p2p because RCCL refuses two ranks on one device
     dev = 0 if os.environ.get("PPLHIP_BENCH_ONE_DEVICE") else local_rank
+    guard.at("pplhip_init (streams, RCCL communicator, buffers)")
     ctx = P.Context(desc, max_running_batch=B, max_tokens_per_step=max(8192, B), n_local_ranks=1, world_size=tp,
                     rank_base=rank, device_ids=[dev], unique_id=uid, profiling=1 if args.breakdown else 2, tpb=args.tpb)
     if world > 1 and os.environ.get("PPLHIP_COMM") != "rccl":
         # one process per GPU: exchange the IPC handles of the exchange regions, then the collective self-test decides
         # between the direct kernels and RCCL (the same decision on every rank)
         handles = [None] * world
+        guard.at("IPC-handle exchange")
         try:
             mine = ctx.comm_export(0)
         except RuntimeError as e:   # no IPC handle for the exchange region on this rank: every rank then stays on RCCL
@@ -353,18 +433,22 @@ def main():
             mine = None
         dist.all_gather_object(handles, mine)
         if all(h is not None for h in handles):
+            guard.at("pplhip_comm_connect (peer mapping + collective self-test)")
             ctx.comm_connect(handles)
     comm_mode = {0: "none", 1: "rccl", 2: "direct xGMI kernels (two-shot, all links)"}[ctx.comm_mode()]
     # what this run's collectives are and cost (outside the timed region): mode, self-test verdict, schedule of the timed step, fallbacks
     # taken, and a timed micro-loop of the step's own all-reduce message on the chosen path AND on RCCL -- so that a bad scaling curve can
     # be read from the JSON line alone
     collectives = ctx.comm_info(B)
+    guard.info = collectives
+    guard.at("timed all-reduce micro-loop")
     if world > 1 or os.environ.get("PPLHIP_FORCE_COMM"):
         try:
             collectives["allreduce_us"] = {"rows": B, "bytes": B * desc.hidden_dim * 2, "chosen_path": ctx.comm_allreduce_us(B, 20, 0),
                                            "rccl": ctx.comm_allreduce_us(B, 20, 1)}
         except Exception as e:   # reporting only
             collectives["allreduce_us"] = {"error": repr(e)}
+    guard.at("weights and KV slab")
     ctx.init_synthetic(0, 1234)
     kv_tokens = B * total_len if args.cache_mode == 0 else B * ((total_len + 15) // 16) * 16
     rag_kv = ragged_kv_lengths(B) if (args.ragged_steps > 0 and args.cache_mode == 0) else None
@@ -401,9 +485,11 @@ def main():
         out, _ = ctx.sample(B, top_k=1, req_list_changed=(i == 0))
         return out.astype(np.int64)
 
+    guard.at("warm-up steps")
     for i in range(W):
         tok = step(i, tok)
     barrier()
+    guard.disarm()   # every rank is past its first steps: from here a failure is a step failure and raises as such
     ctx.profile_reset(0)
     t0 = time.perf_counter()
     for i in range(W, W + K):

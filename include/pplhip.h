@@ -169,6 +169,10 @@ PPLHIP_API int pplhip_comm_export(pplhip_ctx* ctx, int rank, void* handle_out /*
 PPLHIP_API int pplhip_comm_connect(pplhip_ctx* ctx, const void* all_handles /* world_size x PPLHIP_IPC_HANDLE_BYTES */);
 /* collectives in use: 0 none (single rank), 1 RCCL, 2 direct kernels over peer-mapped memory */
 PPLHIP_API int pplhip_comm_mode(pplhip_ctx* ctx);
+/* 1 when the all-reduces behind wo / w2 also do the residual add and the RMSNorm that consumes them, on the rows a rank owns between the two
+ * shots of the direct all-reduce (sequence-parallel residual stream: 1 / world_size of the norm work per rank, one launch less per
+ * half-layer; the same bytes on the links).  Direct collectives only; RCCL keeps all-reduce + replicated norm.  PPLHIP_TP_FUSE_NORM=0: off */
+PPLHIP_API int pplhip_comm_fused_norm(pplhip_ctx* ctx);
 
 /* What a multi-GPU run actually does, for the benchmark's report and for diagnosing a first run on real links (no counterpart in the
  * reference, whose NCCL set-up either works or aborts: src/backends/cuda/resource_manager.cc:392-422).  Fallbacks are never silent: each
@@ -185,7 +189,8 @@ typedef struct pplhip_comm_info_t {
 } pplhip_comm_info_t;
 PPLHIP_API int pplhip_comm_info(pplhip_ctx* ctx, int64_t rows, pplhip_comm_info_t* out);
 /* average microseconds of one all-reduce of fp16 [rows, hidden_dim] (the step's own message) on `rank`'s stream over `iters` calls;
- * path 0: the collectives in use, 1: RCCL.  *us = -1 when that path does not exist.  Collective: every rank calls it alike. */
+ * path 0: the collectives in use, 1: RCCL.  *us = -1 when that path does not exist.  Collective: every rank calls it alike -- the call
+ * enqueues and synchronises, so a context holding several local ranks calls it from one thread per rank at the same time. */
 PPLHIP_API int pplhip_comm_allreduce_us(pplhip_ctx* ctx, int rank, int64_t rows, int32_t iters, int32_t path, float* us);
 
 PPLHIP_API const char* pplhip_last_error(pplhip_ctx* ctx, int rank);
@@ -205,12 +210,6 @@ PPLHIP_API int pplhip_rank_set_tensor(pplhip_ctx* ctx, int rank, const char* nam
 /* fills every weight of this rank's slice on the device from the counter-based generator that
  * oracle/llama_ref.c restates (synthetic weights for benchmarks and parity tests). */
 PPLHIP_API int pplhip_rank_init_synthetic(pplhip_ctx* ctx, int rank, uint64_t seed);
-
-/* a synthetic model whose greedy answers have a wide top-2 margin (token t is followed by t + shift): the embedding table regenerated
- * from `seed` at amplitude embed_amp (0: kept) and output.weight[v] := tok_embeddings.weight[(v - shift) mod vocab] on this rank's shard.
- * For harness checks that compare the answers of two runs token for token (tools/benchmark_prefix_cache_offline
- * --synthetic-decisive-head; the reference compares nothing: benchmark_prefix_cache_offline.cc:442-508). */
-PPLHIP_API int pplhip_rank_tie_output(pplhip_ctx* ctx, int rank, int64_t shift, uint64_t seed, float embed_amp);
 
 /* ================================================================================================
  * KV cache slab -- replaces the cudaMemGetInfo/cudaMalloc block of InitTask
@@ -252,11 +251,6 @@ PPLHIP_API int pplhip_set_inputs(pplhip_ctx* ctx, int rank, const pplhip_step* s
 PPLHIP_API int pplhip_run(pplhip_ctx* ctx, int rank, int cache_prefill);
 
 /* device pointer + row stride (floats) of `logits fp32[B, vocab]` of the last run (llm_engine.cc:207-222). */
-/* Diagnosis (tests bisect a logits difference per layer with it): pplhip_run with the residual stream captured after every
- * layer in the oracle's convention: out[0] = embeddings, out[l+1] = fp16(h + FFN output of layer l), fp32 [L+1, T, hidden].
- * Launches eagerly and synchronises the rank's stream.  Not used by any backend. */
-PPLHIP_API int pplhip_debug_run_dump(pplhip_ctx* ctx, int rank, float* hidden_dump_host);
-
 PPLHIP_API int pplhip_logits(pplhip_ctx* ctx, int rank, float** logits_device, int64_t* stride);
 
 /* test/debug: synchronises the rank's stream and copies the logits [batch, vocab] to host. */
@@ -297,6 +291,23 @@ PPLHIP_API int pplhip_profile_mode(pplhip_ctx* ctx, int mode);
 
 /* free / total device memory of the rank's device (cudaMemGetInfo in llm_generator.cc:777). */
 PPLHIP_API int pplhip_mem_info(pplhip_ctx* ctx, int rank, uint64_t* free_bytes, uint64_t* total_bytes);
+
+/* ================================================================================================
+ * TEST AND HARNESS SUPPORT -- not part of the hot path, called by no backend's step (the product boundary is the
+ * sections above).  Everything from here to the end of the header exists for the parity tests, the diagnosis tools and the
+ * benchmark harnesses: the two entry points below and the single-operator entry points that follow.
+ * ============================================================================================== */
+
+/* a synthetic model whose greedy answers have a wide top-2 margin (token t is followed by t + shift): the embedding table regenerated
+ * from `seed` at amplitude embed_amp (0: kept) and output.weight[v] := tok_embeddings.weight[(v - shift) mod vocab] on this rank's shard.
+ * For harness checks that compare the answers of two runs token for token (tools/benchmark_prefix_cache_offline
+ * --synthetic-decisive-head; the reference compares nothing: benchmark_prefix_cache_offline.cc:442-508). */
+PPLHIP_API int pplhip_rank_tie_output(pplhip_ctx* ctx, int rank, int64_t shift, uint64_t seed, float embed_amp);
+
+/* Diagnosis (tests bisect a logits difference per layer with it): pplhip_run with the residual stream captured after every
+ * layer in the oracle's convention: out[0] = embeddings, out[l+1] = fp16(h + FFN output of layer l), fp32 [L+1, T, hidden].
+ * Launches eagerly and synchronises the rank's stream.  Not used by any backend. */
+PPLHIP_API int pplhip_debug_run_dump(pplhip_ctx* ctx, int rank, float* hidden_dump_host);
 
 /* ================================================================================================
  * single-operator entry points (device pointers, caller-provided stream; used by the parity tests to

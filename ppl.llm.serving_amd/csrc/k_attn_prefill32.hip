@@ -414,7 +414,7 @@ hipError_t launch_attn_prefill32(hipStream_t s, const uint16_t* qkv, const KvAdd
 #define P3_LAUNCH(QB, MD, NW_) hipLaunchKernelGGL((attn_prefill32_kernel<QB, MD, NW_>), grid, dim3(NW_ * 64), 0, s, qkv, kv, seq_starts, start_pos, \
                                                   cache_indices, max_pages, b0, H, Hkv, nreq, nqb, out, nullptr, 0)
 #ifdef P3_ABLATE_BUILD  // diagnosis build (profiles/r03_prefill_attention_ablation.md): wrong results, same instruction stream otherwise
-    static const int abl = tune_int("PPLHIP_P32_ABLATE", 0);
+    static const int abl = getenv("PPLHIP_P32_ABLATE") ? atoi(getenv("PPLHIP_P32_ABLATE")) : 0;   // (an ablation build reads its switch itself: no TUNING=1 needed)
 #define P3_ABL(A) if (abl == A && nw == 8) { hipLaunchKernelGGL((attn_prefill32_kernel<8, 0, 8, A>), grid, dim3(512), 0, s, qkv, kv, seq_starts, start_pos, cache_indices, max_pages, b0, H, Hkv, nreq, nqb, out, nullptr, 0); return hipGetLastError(); }
     P3_ABL(1) P3_ABL(2) P3_ABL(3) P3_ABL(7)
 #undef P3_ABL

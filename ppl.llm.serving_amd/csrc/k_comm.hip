@@ -158,6 +158,118 @@ __global__ __launch_bounds__(512) void p2p_allreduce_kernel(P2pPeers peers, int 
     }
 }
 
+// ---- all-reduce fused with the (Skip)RMSNorm that consumes it: the sequence-parallel residual stream (round 6) ------------------------
+// The two-shot all-reduce above leaves rank r, after its first shot, with the reduced sums of ITS 1/N of the buffer -- and then every rank
+// gathers all N slices and runs the SAME residual-add + RMSNorm over all T rows: N-fold replicated work and one more launch per
+// half-layer (7B at tensor-parallel 8, 1024 rows: 2 x 7.4 us of 215 us per layer and rank, profiles/r06_tp8_slice_kernel_stats.csv).
+// Here the slices are whole ROWS (rank r owns rows [r per, (r + 1) per), per = ceil(rows / N)) and the owner does the rest of the
+// half-layer's element-wise work on them between the shots:
+//     1. start barrier
+//     2. for each owned row: pull the N partial-sum rows (peer reads over the N - 1 links at once), s = fp16(sum in rank order) -- the
+//        all-reduce's arithmetic; r = fp16(h + s) -> h (the residual stream: each rank keeps ONLY its own rows of it from here on);
+//        y = fp16(r * rsqrt(mean(r^2) + eps) * w) -> the local normed matrix AND the rank's scratch slice (system-scope stores)
+//     3. middle barrier
+//     4. gather: every rank pulls the NORMED rows of the other owners into its local matrix (ordinary stores)
+// The same bytes cross the links as before (reduce-scatter + all-gather of fp16 [rows, hidden]); the norm runs on 1/N of the rows; the
+// next GEMM starts from the gathered matrix.  A block handles whole rows (the norm is a row reduction) and block b gathers exactly the
+// rows block b of the owner produced, so the per-block cross-rank barriers of the plain kernel still order everything.
+// N = 1 ("solo"): no peers, no barriers, every row owned -- the self-test's local reference (same arithmetic, bit for bit).
+template <int N>
+__global__ __launch_bounds__(512) void p2p_allreduce_norm_kernel(P2pPeers peers, int me, int n_rt, size_t data_off, size_t scratch_off,
+                                                                 int64_t rows, int chunks /* hidden / 8, <= 1024 */, int hidden,
+                                                                 uint4* h, const uint4* __restrict__ w, float eps, uint4* __restrict__ xn,
+                                                                 uint32_t epoch, u64 timeout_ticks, uint32_t* status, size_t flags_off) {
+    constexpr int MC = 2;                                  // chunks (8 fp16) of a row per thread
+    const int n = N > 0 ? N : n_rt;
+    constexpr int MAXN = N > 0 ? N : P2P_MAX_RANKS;
+    __shared__ float red[8];
+    const int64_t per = (rows + n - 1) / n;
+    const int64_t lo = N == 1 ? 0 : per * me, hi = (lo + per < rows) ? lo + per : rows;   // (solo: every row, whatever the rank's number)
+    const int t = threadIdx.x;
+    if (N != 1) cross_rank_barrier<false>(peers, me, n, P2P_FLAGS_START + flags_off, epoch, timeout_ticks, status);
+    char* mine = peers.base[me] + scratch_off;
+    for (int64_t row = lo + blockIdx.x; row < hi; row += gridDim.x) {
+        float v[MC][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < MC; ++i) {
+            const int c = t + i * 512;
+            if (i * 512 < chunks) {                        // (block-uniform: the batched loads below are unconditional per lane)
+                const int cc = c < chunks ? c : chunks - 1;
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if constexpr (N == 1) {
+                    unpack8(*reinterpret_cast<const uint4*>(peers.base[me] + data_off + (row * chunks + cc) * 16), acc);
+                } else {
+                    u32x4 p[MAXN];
+                    const void* src[MAXN];
+#pragma unroll
+                    for (int r = 0; r < MAXN; ++r) src[r] = peers.base[r < n ? r : me] + data_off + (row * chunks + cc) * 16;
+                    ld_sys16_batch<MAXN>(p, src);
+#pragma unroll
+                    for (int r = 0; r < MAXN; ++r)
+                        if (r < n) add8(acc, p[r]);        // rank order 0 .. n-1: p2p_allreduce_kernel's sum
+                }
+                float hx[8];
+                unpack8(h[row * chunks + cc], hx);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[i][j] = round_h(hx[j] + round_h(acc[j]));   // fp16(h + fp16(sum)): all-reduce, then SkipRMSNorm's add
+                if (c < chunks) {
+                    h[row * chunks + c] = pack8(v[i]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ss += v[i][j] * v[i][j];
+                }
+            }
+        }
+        uint4 wraw[MC];
+#pragma unroll
+        for (int i = 0; i < MC; ++i) {
+            const int c = t + i * 512;
+            wraw[i] = c < chunks ? w[c] : make_uint4(0, 0, 0, 0);
+        }
+        ss = wave_sum(ss);
+        if ((t & 63) == 0) red[t >> 6] = ss;
+        __syncthreads();
+        ss = red[0] + red[1] + red[2] + red[3];
+#pragma unroll
+        for (int wv = 4; wv < 8; ++wv) ss += red[wv];
+        const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
+#pragma unroll
+        for (int i = 0; i < MC; ++i) {
+            const int c = t + i * 512;
+            if (c < chunks) {
+                float wf[8], o[8];
+                unpack8(wraw[i], wf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = v[i][j] * inv * wf[j];
+                const uint4 y = pack8(o);
+                xn[row * chunks + c] = y;
+                if (N != 1) st_sys16(mine + ((row - lo) * chunks + c) * 16, __builtin_bit_cast(u32x4, y));
+            }
+        }
+        __syncthreads();                                   // red is reused by the next row
+    }
+    if constexpr (N != 1) {
+    cross_rank_barrier<true>(peers, me, n, P2P_FLAGS_MID + flags_off, epoch, timeout_ticks, status);
+    for (int64_t j = blockIdx.x; j < per; j += gridDim.x) {   // local row j of every owner: written there by ITS block blockIdx.x
+#pragma unroll
+        for (int i = 0; i < MC; ++i) {
+            const int c = t + i * 512;
+            if (i * 512 < chunks) {
+                const int cc = c < chunks ? c : chunks - 1;
+                u32x4 p[MAXN];
+                const void* src[MAXN];
+#pragma unroll
+                for (int r = 0; r < MAXN; ++r) src[r] = peers.base[r < n ? r : me] + scratch_off + (j * chunks + cc) * 16;
+                ld_sys16_batch<MAXN>(p, src);
+#pragma unroll
+                for (int r = 0; r < MAXN; ++r)
+                    if (r < n && r != me && c < chunks && per * r + j < rows) xn[(per * r + j) * chunks + c] = __builtin_bit_cast(uint4, p[r]);
+            }
+        }
+    }
+    }
+}
+
 // logits shards: rows x row_granules granules (G = 8 or 16 bytes) at src_off of every rank's region (rank r's [rows, V/n] block)
 // -> columns [r * row_granules, (r + 1) * row_granules) of my [rows, dst_row_granules] matrix (ordinary local memory)
 template <int GB>
@@ -265,6 +377,25 @@ hipError_t launch_p2p_allreduce(hipStream_t s, const P2pPeers& peers, int me, in
 #define AR(NN) hipLaunchKernelGGL(p2p_allreduce_kernel<NN>, grid, block, 0, s, peers, me, n, data_off, scratch_off, granules, epoch, (u64)timeout_ticks, status, flags_off)
     if (n == 2) AR(2); else if (n == 4) AR(4); else if (n == 8) AR(8); else AR(0);
 #undef AR
+    return hipGetLastError();
+}
+
+hipError_t launch_p2p_allreduce_norm(hipStream_t s, const P2pPeers& peers, int me, int n, size_t data_off, size_t scratch_off, int64_t rows,
+                                     int hidden, uint16_t* h, const uint16_t* w, float eps, uint16_t* xn, uint32_t epoch, uint64_t timeout_ticks,
+                                     uint32_t* status, int channel) {
+    if (n < 1 || n > P2P_MAX_RANKS || hidden % 8 || hidden > P2P_NORM_MAX_HIDDEN || data_off % 16 || scratch_off % 16 || channel < 0 || channel >= P2P_CHANNELS)
+        return hipErrorInvalidValue;
+    if (rows == 0) return hipSuccess;
+    const size_t flags_off = (size_t)channel * P2P_CHANNEL_FLAG_BYTES;
+    const int64_t per = (rows + n - 1) / n;
+    static const int cap = tune_int("PPLHIP_P2P_BLOCKS", 32);
+    const int c = cap < 1 ? 1 : (cap > P2P_MAX_BLOCKS ? P2P_MAX_BLOCKS : cap);
+    // one block per owned row up to the cap (the same count on every rank: the cross-rank barriers pair block b with block b); solo: every row
+    const dim3 grid((unsigned)(n == 1 ? (rows < 256 ? rows : 256) : (per < c ? per : c))), block(512);
+#define ARN(NN) hipLaunchKernelGGL(p2p_allreduce_norm_kernel<NN>, grid, block, 0, s, peers, me, n, data_off, scratch_off, rows, hidden / 8, hidden, \
+                                   (uint4*)h, (const uint4*)w, eps, (uint4*)xn, epoch, (u64)timeout_ticks, status, flags_off)
+    if (n == 1) ARN(1); else if (n == 2) ARN(2); else if (n == 4) ARN(4); else if (n == 8) ARN(8); else ARN(0);
+#undef ARN
     return hipGetLastError();
 }
 

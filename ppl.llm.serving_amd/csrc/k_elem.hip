@@ -21,6 +21,19 @@ hipError_t launch_embedding(hipStream_t s, const int64_t* token_ids, const uint1
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void gather_last_rows_kernel(const int64_t* __restrict__ seq_starts, const uint4* __restrict__ x, int chunks,
+                                                               uint4* __restrict__ out) {
+    const int64_t r = blockIdx.x, src = seq_starts[r + 1] - 1;
+    for (int c = threadIdx.x; c < chunks; c += 256) out[r * chunks + c] = x[src * chunks + c];
+}
+
+hipError_t launch_gather_last_rows(hipStream_t s, const uint16_t* x, const int64_t* seq_starts, int64_t B, int hidden, uint16_t* out) {
+    if (B == 0) return hipSuccess;
+    if (hidden % 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gather_last_rows_kernel, dim3((unsigned)B), dim3(256), 0, s, seq_starts, (const uint4*)x, hidden / 8, (uint4*)out);
+    return hipGetLastError();
+}
+
 // Each thread keeps up to MAXC chunks of its row in registers (hidden <= 256*8*MAXC); larger rows re-read.
 // NT threads per row: 256, or -- steps of a few hundred rows at most, where the launch is one block per CU or less and a row is a chain of
 // latencies (load, reduce, barrier, store) rather than bandwidth -- 512 / 1024 with one chunk per thread (launch_rmsnorm)
@@ -139,11 +152,15 @@ hipError_t launch_rmsnorm(hipStream_t s, const uint16_t* x, const uint16_t* skip
     hipLaunchKernelGGL(rmsnorm_kernel<MC>, g, b, 0, s, (const uint4*)x, (const uint4*)skip, (const uint4*)w, eps,   \
                        chunks, hidden, gather_seq_starts, (uint4*)out, (uint4*)residual_out, qout, sx, sl)
     // few rows of a wide model (decode steps of 5..512 rows at hidden >= 4096): one chunk per thread on 512 / 1024 threads -- every load of
-    // the row is in flight at once.  (Up to 4 rows stay on the 256-thread form: the fused GEMV norm of k_gemv.hip restates ITS summation order.)
-    // -1.9 % on config 4's per-rank step and -0.4..-1.7 % on 7B steps of 8-512 rows (profiles/r04_rmsnorm_wide_ab.log).  Round 4 kept it
-    // opt-in: its summation order moved the 70B / TP8 W4A16 parity case over its fixed cap -- a case that the grouped-query decode kernel's
-    // rounded V had already brought to 0.90 of that cap; with V exact again (k_attn_decode_gqa.hip, round 5) the case sits at 0.89e-3 = 1.27 x
-    // the oracle's noise floor WITH this form (profiles/r05_w4_gqa_margin.log).  PPLHIP_RMSNORM_WIDE_MAX_ROWS=0: the 256-thread form (A/B runs)
+    // the row is in flight at once.  -1.9 % on config 4's per-rank step and -0.4..-1.7 % on 7B steps of 8-512 rows
+    // (profiles/r04_rmsnorm_wide_ab.log).  The two forms sum a row's squares in different orders, so a token's norm -- and in the last bits
+    // its logits -- depend on the step's row count class (<= 4, 5..512, > 512; the 512-row halves of a two-stream step): the same kind of
+    // dependence as the GEMM tile choice by M, inside the specification's noise floor, guarded by the greedy-token tests
+    // (tests/test_gpu_config5_tokens.py, test_gpu_model.py).  Up to 4 rows stay on the 256-thread form only because a block of 1024
+    // threads per row buys nothing there.  Round 4 kept the wide form opt-in: its summation order moved the 70B / TP8 W4A16 parity case
+    // over its fixed cap -- a case that the grouped-query decode kernel's rounded V had already brought to 0.90 of that cap; with V exact
+    // again (k_attn_decode_gqa.hip, round 5) the case sits at 0.89e-3 = 1.27 x the oracle's noise floor WITH this form
+    // (profiles/r05_w4_gqa_margin.log).  PPLHIP_RMSNORM_WIDE_MAX_ROWS=0: the 256-thread form (A/B runs)
     static const int wide_rows = getenv("PPLHIP_RMSNORM_WIDE_MAX_ROWS") ? atoi(getenv("PPLHIP_RMSNORM_WIDE_MAX_ROWS")) : 512;
     if (rows > 4 && rows <= wide_rows && chunks >= 512 && chunks <= 1024 && chunks % 64 == 0) {
         if (chunks <= 512) hipLaunchKernelGGL((rmsnorm_kernel<1, 512>), g, dim3(512), 0, s, (const uint4*)x, (const uint4*)skip, (const uint4*)w, eps,

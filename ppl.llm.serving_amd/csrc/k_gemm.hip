@@ -707,7 +707,7 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
     // step, 12.70 -> 12.49 ms (profiles/r05_w4_pc_experiments.md).  PPLHIP_GEMM_PC=0: the ring kernel for everything (A/B runs)
     static const int pc_mode = getenv("PPLHIP_GEMM_PC") ? atoi(getenv("PPLHIP_GEMM_PC")) : 1;
     if (pc_mode && wq_bit == 4 && M > 128 && M <= 512 && !force_generic && (int64_t)((N + 63) / 64) * ((M + 127) / 128) >= 160 &&
-        linear_w4_pc_supported(group, M, N, K, y, ldy, epi))
+        linear_w4_pc_supported(group, M, N, K, x, w, scale, y, ldy, epi))
         return launch_linear_w4_pc(s, x, w, scale, M, N, K, y, ldy, epi);
     // W8A16 at 512 <= M < 4096 with N >= 8192 (wqkv / w13 of a decode step at batch ~1024): one 128 x 384 block per CU whose twelve
     // consumer waves share the activation tile (k_gemm_wide.hip) when its tiles fill the chip's rounds; PPLHIP_GEMM_WIDE=0: never
@@ -719,6 +719,13 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
         static const int asm_loop = getenv("PPLHIP_GEMM_ASM") ? atoi(getenv("PPLHIP_GEMM_ASM")) : 0;
         if (nc && asm_loop) return launch_linear_w8_asm(s, x, (const int8_t*)w, scale, M, N, K, y, ldy, epi);
         if (nc) return launch_linear_w8_wide(s, x, (const int8_t*)w, scale, M, N, K, y, ldy, epi, nc);
+    }
+    // W8A16 slices of a tensor-parallel step (512 <= M <= 1024) whose 128 x 128 tiles leave a quarter of the CUs idle or need K slabs, while
+    // 128 x 96 / 64 x 96 tiles fill one round of 256 blocks: the k-split kernel of k_gemm_ks.hip (7B at tensor-parallel 8: wqkv, w13; at 4: wqkv)
+    if (wq_bit == 8 && epi != EPI_F32 && !force_generic && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)scale & 7) == 0 &&
+        ((uintptr_t)y & 7) == 0) {
+        const int tile = linear_w8_ks_tile(M, N, K);
+        if (tile) return launch_linear_w8_ks(s, x, (const int8_t*)w, scale, M, N, K, y, ldy, epi, tile);
     }
     const int n_tiles = (N + G_BN - 1) / G_BN;
     const int m_tiles = (int)((M + G_BM - 1) / G_BM);

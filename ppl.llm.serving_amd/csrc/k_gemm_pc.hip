@@ -368,11 +368,13 @@ __global__ __launch_bounds__(512) void gemm_w4_pc_kernel(const uint16_t* __restr
 
 // Shapes this kernel takes: int4 weights in groups of 128, K % 128 == 0, N % 4 == 0 (N % 16 == 0 with the fused SwiGLU), 16-byte aligned
 // output rows, 32-bit byte offsets inside x and w.
-bool linear_w4_pc_supported(int group, int64_t M, int N, int K, const void* y, int64_t ldy, int epi) {
+bool linear_w4_pc_supported(int group, int64_t M, int N, int K, const void* x, const void* w, const void* scale, const void* y, int64_t ldy, int epi) {
     if (group != 128 || K % 128 || K < 128 || N % 4 || M < 1) return false;
     if (epi != EPI_F16 && epi != EPI_SWIGLU) return false;
     if (epi == EPI_SWIGLU && N % 16) return false;
     if (ldy % 8 || ((uintptr_t)y & 15)) return false;
+    // the LDS-DMA fetches x and w in 16-byte pieces and the scale as the aligned dword around fp16 element n G + g
+    if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)scale & 3)) return false;
     if ((uint64_t)M * (uint64_t)K * 2 >= (1ull << 32) || (uint64_t)N * (uint64_t)K / 2 >= (1ull << 32)) return false;
     if ((uint64_t)N * (uint64_t)(K / 128) >= (1ull << 30)) return false;
     return true;

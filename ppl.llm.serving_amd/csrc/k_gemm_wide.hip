@@ -188,7 +188,7 @@ hipError_t launch_linear_w8_wide(hipStream_t s, const uint16_t* x, const int8_t*
     }
     dim3 grid((unsigned)((n_tiles + 7) / 8 * 8 * m_tiles));
 #ifdef WD_ABLATE_BUILD  // diagnosis (wrong results): PPLHIP_GEMM_WIDE_ABLATE = 1 no refills, 2 no conversion, 4 one activation row, 8 no barriers
-    static const int abl = tune_int("PPLHIP_GEMM_WIDE_ABLATE", 0);
+    static const int abl = getenv("PPLHIP_GEMM_WIDE_ABLATE") ? atoi(getenv("PPLHIP_GEMM_WIDE_ABLATE")) : 0;   // (an ablation build reads its switch itself: no TUNING=1 needed)
 #define WD_AB(A) if (abl == A) { (void)hipFuncSetAttribute((const void*)gemm_w8_wide_kernel<EPI_F16, ST, 12, A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((gemm_w8_wide_kernel<EPI_F16, ST, 12, A>), grid, dim3((12 + WD_NP) * 64), lds, s, x, w, scale, M, N, K, y, ldy, n_tiles, m_tiles); return hipGetLastError(); }
     WD_AB(1) WD_AB(2) WD_AB(3) WD_AB(4) WD_AB(6) WD_AB(7) WD_AB(8) WD_AB(15)

@@ -60,6 +60,8 @@ hipError_t launch_rmsnorm(hipStream_t s, const uint16_t* x, const uint16_t* skip
                           uint16_t* residual_out, int8_t* qout = nullptr, float* sx = nullptr,
                           const SplitSlabs* skip_slabs = nullptr);  // skip_slabs: the skip operand as unreduced split-K slabs
 hipError_t launch_silu_mul(hipStream_t s, const uint16_t* gate_up, int64_t T, int inter, uint16_t* out);
+// out[r] = x[seq_starts[r + 1] - 1] (last-token gather of K11 when the final norm already ran on every row: fused tensor-parallel norm)
+hipError_t launch_gather_last_rows(hipStream_t s, const uint16_t* x, const int64_t* seq_starts, int64_t B, int hidden, uint16_t* out);
 
 // ---- k_rope_kv.hip ----------------------------------------------------------------------------
 hipError_t launch_rope_kv_write(hipStream_t s, uint16_t* qkv, const float* cos_sin, const KvAddr& kv, int quant_bit,
@@ -112,9 +114,14 @@ hipError_t launch_linear_w8_wide(hipStream_t s, const uint16_t* x, const int8_t*
 hipError_t launch_linear_w8_asm(hipStream_t s, const uint16_t* x, const int8_t* w, const uint16_t* scale, int64_t M, int N, int K, void* y,
                                 int64_t ldy, int epi);
 // W4A16 (group 128) on 128 (m) x 64 (n) tiles, no K slabs (k_gemm_pc.hip): a few hundred rows; epi 0 fp16 / 2 fused SwiGLU
-bool linear_w4_pc_supported(int group, int64_t M, int N, int K, const void* y, int64_t ldy, int epi);
+bool linear_w4_pc_supported(int group, int64_t M, int N, int K, const void* x, const void* w, const void* scale, const void* y, int64_t ldy, int epi);
 hipError_t launch_linear_w4_pc(hipStream_t s, const uint16_t* x, const void* w, const uint16_t* scale, int64_t M, int N, int K, void* y,
                                int64_t ldy, int epi);
+// W8A16 on k-split tiles (k_gemm_ks.hip): the per-rank slices of a tensor-parallel decode step whose 128 x 128 tiles would leave CUs idle.
+// linear_w8_ks_tile: 0 none, 1 128 (m) x 96 (n), 2 64 x 96; epi 0 fp16 / 2 fused SwiGLU
+int linear_w8_ks_tile(int64_t M, int N, int K);
+hipError_t launch_linear_w8_ks(hipStream_t s, const uint16_t* x, const int8_t* w, const uint16_t* scale, int64_t M, int N, int K, void* y,
+                               int64_t ldy, int epi, int tile);
 int linear_w8_wide_waves(int64_t M, int N);  // 12 when the 128 x 384 tiles fill rounds of 256 blocks well enough, else 0
 hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const uint16_t* scale, int wq_bit, int group,
                          int64_t M, int N, int K, void* y, int64_t ldy, bool out_fp32, float* ws = nullptr, size_t ws_bytes = 0,
@@ -156,6 +163,15 @@ struct P2pPeers {
 // offset with room for ceil(count / n) fp16 that no other collective in flight uses
 hipError_t launch_p2p_allreduce(hipStream_t s, const P2pPeers& peers, int me, int n, size_t data_off, size_t scratch_off, int64_t count,
                                 uint32_t epoch, uint64_t timeout_ticks, uint32_t* status, int channel = 0);   // epochs count per channel
+// The same all-reduce fused with the residual add + RMSNorm that consumes it (sequence-parallel residual stream, k_comm.hip): `rows` rows of
+// fp16 [rows, hidden] partial sums at data_off of every rank's region; rank `me` owns rows [me per, (me + 1) per), per = ceil(rows / n): on those
+// it computes s = fp16(sum over ranks), h = fp16(h + s) (h: LOCAL residual rows, only the owned ones are read or written) and
+// y = rmsnorm(h) * w; every rank ends with all rows of y in the local matrix xn.  scratch_off: room for per rows.  n == 1: local reference
+// form (no peers, no barriers, every row owned; reads data_off of the own region).  hidden <= P2P_NORM_MAX_HIDDEN, hidden % 8 == 0
+constexpr int P2P_NORM_MAX_HIDDEN = 8192;
+hipError_t launch_p2p_allreduce_norm(hipStream_t s, const P2pPeers& peers, int me, int n, size_t data_off, size_t scratch_off, int64_t rows,
+                                     int hidden, uint16_t* h, const uint16_t* w, float eps, uint16_t* xn, uint32_t epoch, uint64_t timeout_ticks,
+                                     uint32_t* status, int channel = 0);
 // rows x row_bytes at src_off of every rank's region (rank r's column block) -> columns [r * row_bytes, ...) of the local
 // [rows, dst_row_bytes] matrix dst (ordinary memory)
 hipError_t launch_p2p_allgather(hipStream_t s, const P2pPeers& peers, int me, int n, size_t src_off, void* dst, int64_t rows,

@@ -179,6 +179,13 @@ struct pplhip_ctx {
     int dual_mode = -1;
     bool dual_auto = false;          // the automatic rule is in force (row window 512..1024)
     int64_t dual_min_rows = 96, dual_max_rows = 512;
+    // Sequence-parallel residual stream (round 6): on the direct collectives the all-reduce behind wo / w2 also does the residual add and the
+    // RMSNorm that consumes it, on the rows the rank owns after the first shot, and the second shot gathers NORMED rows (k_comm.hip
+    // p2p_allreduce_norm_kernel): 1 / tp of the norm work per rank and one launch less per half-layer.  Each rank then keeps only its own
+    // rows of the residual stream h.  Not with int8 activations (the norm writes the quantised operand there), residual dumps, RCCL
+    // (plain all-reduce + replicated norm as before) or hidden > 8192.  PPLHIP_TP_FUSE_NORM=0: off (A/B runs)
+    bool fuse_norm_want = true;
+    bool emulate_tp = false;         // PPLHIP_EMULATE_TP (bench.py --emulate-tp): one rank's slice, collectives are local identities
     int selftest = 0;                // direct collectives' start-up self-test: 0 not run, 1 passed on every rank, -1 failed (RCCL in charge)
     std::string comm_notes;          // every fallback taken at start-up, in order (never silent: also on stderr)
     bool graph_on = false;           // PPLHIP_DECODE_GRAPH=1: replay pure-decode steps as HIP graphs (opt-in, see run_decode_graph)
@@ -420,6 +427,48 @@ int p2p_selftest(pplhip_ctx* c, const std::string* local_failure = nullptr) {
                     }
         }
     }
+    // the fused all-reduce + residual add + RMSNorm (p2p_allreduce_norm_kernel, what a step issues when fuse_norm_active): against a LOCAL
+    // reference built from parts that are already verified -- the plain all-reduce above leaves the exact sums on every rank, the kernel's
+    // own one-rank form ("solo": same arithmetic, no peers) turns them into the expected residual and normed rows; the real kernel, run on
+    // the unreduced patterns, must then give the same bits in every row it gathered and in the residual rows it owns
+    const int64_t frows = hd > 0 ? cnt / hd : 0;
+    if (ok && c->fuse_norm_want && c->d.act_quant_bit != 8 && hd % 8 == 0 && hd <= P2P_NORM_MAX_HIDDEN && frows >= 1 &&
+        c->ranks[0].gemm_ws_bytes >= (size_t)frows * hd * 4 + (size_t)hd * 2) {
+        const int64_t fcnt = frows * hd;
+        std::vector<uint16_t> want_x(fcnt), want_h(fcnt);
+        for (int round = 0; round < 2 && ok; ++round) {
+            for (int r = 0; r < n; ++r) {
+                Rank& R = c->ranks[r];
+                HIPCK(c, r, hipSetDevice(R.device));
+                uint16_t* xref = (uint16_t*)R.gemm_ws, *href = xref + fcnt, *w = href + fcnt;
+                HIPCK(c, r, launch_p2p_pattern(R.stream, R.part, fcnt, nullptr, 0, R.global_rank, round + 4));
+                HIPCK(c, r, launch_p2p_allreduce(R.stream, R.peers, R.global_rank, tp, R.x_part, R.x_scratch[R.ar_count++ & 1], fcnt, ++R.p2p_epoch, ticks, R.p2p_status));
+                HIPCK(c, r, launch_p2p_pattern(R.stream, R.h, fcnt, nullptr, 0, 17, round + 4));    // the residual stream: the same on every rank
+                HIPCK(c, r, launch_p2p_pattern(R.stream, w, hd, nullptr, 0, 23, round + 4));
+                HIPCK(c, r, hipMemcpyAsync(href, R.h, (size_t)fcnt * 2, hipMemcpyDeviceToDevice, R.stream));
+                HIPCK(c, r, launch_p2p_allreduce_norm(R.stream, R.peers, R.global_rank, 1, R.x_part, 0, frows, hd, href, w, c->d.norm_eps, xref, 0, ticks, R.p2p_status));
+                HIPCK(c, r, launch_p2p_pattern(R.stream, R.part, fcnt, nullptr, 0, R.global_rank, round + 4));
+                HIPCK(c, r, launch_p2p_allreduce_norm(R.stream, R.peers, R.global_rank, tp, R.x_part, R.x_scratch[R.ar_count++ & 1], frows, hd, R.h, w, c->d.norm_eps,
+                                                      R.xn, ++R.p2p_epoch, ticks, R.p2p_status));
+            }
+            for (int r = 0; r < n && ok; ++r) {
+                Rank& R = c->ranks[r];
+                HIPCK(c, r, hipSetDevice(R.device));
+                HIPCK(c, r, hipStreamSynchronize(R.stream));
+                if (*R.p2p_status) { ok = false; why = "fused all-reduce + norm: spin timed out (status " + std::to_string(*R.p2p_status) + ")"; *R.p2p_status = 0; break; }
+                HIPCK(c, r, hipMemcpy(want_x.data(), R.gemm_ws, (size_t)fcnt * 2, hipMemcpyDeviceToHost));
+                HIPCK(c, r, hipMemcpy(want_h.data(), (uint16_t*)R.gemm_ws + fcnt, (size_t)fcnt * 2, hipMemcpyDeviceToHost));
+                HIPCK(c, r, hipMemcpy(hbuf.data(), R.xn, (size_t)fcnt * 2, hipMemcpyDeviceToHost));
+                int64_t bad = 0, first = -1;
+                for (int64_t i = 0; i < fcnt; ++i) if (hbuf[i] != want_x[i]) { if (!bad) first = i; ++bad; }
+                if (bad) { ok = false; why = "fused all-reduce + norm: " + std::to_string(bad) + "/" + std::to_string(fcnt) + " normed values differ on rank " + std::to_string(R.global_rank) + " (first: row " + std::to_string(first / hd) + ")"; break; }
+                const int64_t per = (frows + tp - 1) / tp, lo = std::min<int64_t>(per * R.global_rank, frows), hi = std::min<int64_t>(lo + per, frows);
+                HIPCK(c, r, hipMemcpy(hbuf.data(), R.h, (size_t)fcnt * 2, hipMemcpyDeviceToHost));
+                for (int64_t i = lo * hd; i < hi * hd; ++i) if (hbuf[i] != want_h[i]) { ++bad; }
+                if (bad) { ok = false; why = "fused all-reduce + norm: " + std::to_string(bad) + " residual values of the owned rows differ on rank " + std::to_string(R.global_rank); break; }
+            }
+        }
+    }
     // agreement: min over all ranks of the group
     if (c->comm_mode == 1) {
         for (int r = 0; r < n; ++r) {
@@ -491,6 +540,8 @@ int p2p_check(pplhip_ctx* c, int rank) {
 }
 
 }  // namespace
+
+static bool fuse_norm_active(const pplhip_ctx* c, const Rank& R);
 
 extern "C" {
 
@@ -622,16 +673,20 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
     const bool want_comm = tp > 1 || getenv("PPLHIP_FORCE_COMM") != nullptr;
     c->tp_on = want_comm;
     if (const char* e = getenv("PPLHIP_DECODE_GRAPH")) c->graph_on = atoi(e) != 0;
+    if (const char* e = getenv("PPLHIP_TP_FUSE_NORM")) c->fuse_norm_want = atoi(e) != 0;
+    c->emulate_tp = getenv("PPLHIP_EMULATE_TP") != nullptr;
     if (const char* e = getenv("PPLHIP_DUAL_STREAM")) c->dual_mode = atoi(e);
+    int dual_min_env = 0;
+    if (const char* e = getenv("PPLHIP_DUAL_MIN_ROWS")) dual_min_env = std::max(2, atoi(e));
     if (c->dual_mode < 0) {   // automatic: only where there is link time to hide
         c->dual_auto = tp > 1 && !getenv("PPLHIP_EMULATE_TP");
         c->dual_mode = c->dual_auto ? 1 : 0;
-        if (c->dual_auto) { c->dual_min_rows = 512; c->dual_max_rows = 1024; }
-        // (no second stream, communicator or workspace for a context whose steps can never reach the window: a whole tp-8 group on ONE
-        // device -- the tests -- already needs 16 hardware queues for its compute and communication streams)
+        if (c->dual_auto) { c->dual_min_rows = dual_min_env ? dual_min_env : 512; c->dual_max_rows = 1024; }
+        // (no second stream or workspace for a context whose steps can never reach the window: memory, not safety -- the safety check is
+        // the stream count against the hardware queues below)
         if (c->dual_auto && opts->max_running_batch < c->dual_min_rows) { c->dual_auto = false; c->dual_mode = 0; }
     }
-    if (const char* e = getenv("PPLHIP_DUAL_MIN_ROWS")) c->dual_min_rows = std::max(2, atoi(e));
+    if (dual_min_env) c->dual_min_rows = dual_min_env;
     if (const char* e = getenv("PPLHIP_DUAL_MAX_ROWS")) c->dual_max_rows = atoi(e);
     if (const char* e = getenv("PPLHIP_DECODE_GRAPH_MAX_BATCH")) c->graph_max_batch = std::max(1, atoi(e));
     if (const char* e = getenv("PPLHIP_COMM")) c->comm_want = !strcmp(e, "rccl") ? 1 : (!strcmp(e, "p2p") ? 2 : 0);
@@ -652,6 +707,38 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
     }
     if (const char* e = getenv("PPLHIP_TP_OVERLAP")) c->tp_overlap = atoi(e) != 0;
     if (const char* e = getenv("PPLHIP_TP_HANDOFF")) c->handoff_flags = strcmp(e, "events") != 0;
+    {   // Streams against hardware queues.  Kernels of this library WAIT for kernels on other streams of the same process (direct collectives
+        // of ranks that share a device, the hand-off kernels of the two-chunk schedule, the halves of a two-stream step meeting in a
+        // collective): the HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues per device (default 4), and a
+        // spinning kernel queued IN FRONT of the kernel it waits for on the same hardware queue never sees it run.  That is what round 5's
+        // "stream hand-off timed out" was (a tp-8 group on ONE device with automatic two-stream decode: 8 x 3 streams on 24 queues).
+        // Checked here as a resource, per device: streams this context will create there against the queues the runtime will give it.
+        const char* q = getenv("GPU_MAX_HW_QUEUES");
+        const int hwq = q && atoi(q) > 0 ? atoi(q) : 4;
+        auto streams_per_rank = [&]() { return 1 + (c->dual_mode ? 1 : 0) + (c->tp_on ? 1 : 0); };
+        int worst = 0;
+        for (int a = 0; a < n; ++a) {
+            int same = 0;
+            for (int b = 0; b < n; ++b) same += devs[a] == devs[b];
+            worst = std::max(worst, same);
+        }
+        if (c->dual_auto && worst * streams_per_rank() > hwq) {
+            comm_note(c.get(), "two-stream decode off: " + std::to_string(worst) + " local rank(s) per device x " + std::to_string(streams_per_rank()) +
+                                   " streams exceed " + std::to_string(hwq) + " hardware queues (GPU_MAX_HW_QUEUES)");
+            c->dual_auto = false;
+            c->dual_mode = 0;
+        }
+        if (c->tp_on && worst * streams_per_rank() > hwq) {
+            if (c->handoff_flags && !getenv("PPLHIP_TP_HANDOFF")) {
+                c->handoff_flags = false;   // events never spin
+                comm_note(c.get(), "stream hand-offs by events, not device flags: " + std::to_string(worst * streams_per_rank()) + " streams on one device exceed " +
+                                       std::to_string(hwq) + " hardware queues");
+            }
+            if (worst > 1)
+                comm_note(c.get(), "warning: " + std::to_string(worst) + " ranks share a device with " + std::to_string(worst * streams_per_rank()) + " streams on " +
+                                       std::to_string(hwq) + " hardware queues -- direct collectives between them can time out (set GPU_MAX_HW_QUEUES)");
+        }
+    }
     if (const char* e = getenv("PPLHIP_TP_OVERLAP_MIN_TOKENS")) c->tp_overlap_min_tokens = std::max(2, atoi(e));
     if (want_comm && c->comm_want != 2) {
         std::vector<ncclComm_t> comms(n);
@@ -672,7 +759,10 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
             NCCLCK(cp, -1, ncclGroupEnd());
         }
         for (int r = 0; r < n; ++r) c->ranks[r].comm = comms[r];
-        if (c->dual_mode) {   // a second communicator over the same ranks for the second stream of a two-stream decode step
+        // a second communicator over the same ranks for the second stream of a two-stream decode step -- only when two-stream decode was
+        // asked for explicitly (PPLHIP_DUAL_STREAM=1): the automatic mode runs on the direct collectives' second channel and never uses it
+        // (run_launches), and two RCCL communicators on one device have never run on two devices
+        if (c->dual_mode && !c->dual_auto) {
             std::vector<ncclComm_t> comms2(n, nullptr);
             ncclResult_t rc2 = ncclGroupStart();
             for (int r = 0; r < n && rc2 == ncclSuccess; ++r) rc2 = ncclCommSplit(comms[r], 0, opts->rank_base + r, &comms2[r], nullptr);
@@ -682,6 +772,7 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
             } else {
                 // ladder: without a second communicator a two-stream step can still run on the direct collectives (their second channel);
                 // on RCCL it falls back to one stream (run_launches checks R.comm2)
+                for (int r = 0; r < n; ++r) if (comms2[r]) (void)ncclCommAbort(comms2[r]);   // partially created group
                 comm_note(c.get(), std::string("second RCCL communicator unavailable (") + ncclGetErrorString(rc2 != ncclSuccess ? rc2 : rc3) +
                                        "): two-stream decode only on the direct collectives, else one stream");
             }
@@ -753,13 +844,15 @@ int pplhip_init(const pplhip_model_desc* desc, const pplhip_opts* opts, pplhip_c
             auto up = [](size_t v) { return (v + 4095) / 4096 * 4096; };
             R.x_part = P2P_DATA_START;
             R.x_part2 = R.x_part + up((size_t)cap_T * hd * 2);
-            R.x_scratch[0] = R.x_part2 + up((size_t)cap_T * hd * 2);          // a rank's reduced slice: <= half the buffer (n >= 2)
-            R.x_scratch[1] = R.x_scratch[0] + up((size_t)cap_T * hd + 64);
-            R.x_local = R.x_scratch[1] + up((size_t)cap_T * hd + 64);
+            // a rank's reduced slice: <= half the buffer (n >= 2) -- as elements (plain all-reduce) or as whole rows (fused norm: ceil(T / 2) rows)
+            const size_t slice_bytes = up(((size_t)cap_T / 2 + 1) * hd * 2 + 64);
+            R.x_scratch[0] = R.x_part2 + up((size_t)cap_T * hd * 2);
+            R.x_scratch[1] = R.x_scratch[0] + slice_bytes;
+            R.x_local = R.x_scratch[1] + slice_bytes;
             if (c->dual_mode) {
                 R.x_scratch2[0] = R.x_local;
-                R.x_scratch2[1] = R.x_scratch2[0] + up((size_t)cap_T * hd + 64);
-                R.x_local = R.x_scratch2[1] + up((size_t)cap_T * hd + 64);
+                R.x_scratch2[1] = R.x_scratch2[0] + slice_bytes;
+                R.x_local = R.x_scratch2[1] + slice_bytes;
             }
             R.xbytes = R.x_local + up((size_t)cap_B * c->vocab_local * 4);
             // FINE-GRAINED device memory: the kind HIP defines as coherent between devices at system scope (what RCCL puts its
@@ -876,6 +969,7 @@ int pplhip_comm_connect(pplhip_ctx* c, const void* all_handles) {
 }
 
 int pplhip_comm_mode(pplhip_ctx* c) { return c ? c->comm_mode : PPLHIP_INVALID_VALUE; }
+int pplhip_comm_fused_norm(pplhip_ctx* c) { return c && !c->ranks.empty() ? (fuse_norm_active(c, c->ranks[0]) ? 1 : 0) : PPLHIP_INVALID_VALUE; }
 
 /* ------------------------------------------------------------------------------------------------ weights */
 
@@ -1249,7 +1343,8 @@ static int layer_linear(pplhip_ctx* c, int rank, const Linear& l, const uint16_t
 }
 
 // attention block of layer l for one chunk: (Skip)RMSNorm -> wqkv -> RoPE + KV write -> attention -> wo (partial sums)
-static int layer_attention_part(pplhip_ctx* c, int rank, int l, const Chunk& k, const uint16_t* pending, int split, int threads) {
+// xn_ready: the fused collective of the previous half-layer already left this block's normalised input in R.xn (and the residual in R.h)
+static int layer_attention_part(pplhip_ctx* c, int rank, int l, const Chunk& k, const uint16_t* pending, int split, int threads, bool xn_ready = false) {
     Rank& R = c->ranks[rank];
     const pplhip_model_desc& d = c->d;
     hipStream_t s = R.stream;
@@ -1261,8 +1356,9 @@ static int layer_attention_part(pplhip_ctx* c, int rank, int l, const Chunk& k, 
     uint16_t* xn = R.xn + k.t0 * hd;
     const bool a8 = d.act_quant_bit == 8;  // the norm writes the int8 operand of the next linear directly (no fp16 xn, no separate pass)
     {
-        HIPCK(c, rank, launch_rmsnorm(s, h, pending ? pending + k.t0 * hd : nullptr, L.attn_norm, d.norm_eps, k.tn, hd, nullptr, xn,
-                                      pending ? h : nullptr, a8 ? R.xq : nullptr, a8 ? R.sx : nullptr, pending ? &R.sl_part2 : nullptr));
+        if (!xn_ready)
+            HIPCK(c, rank, launch_rmsnorm(s, h, pending ? pending + k.t0 * hd : nullptr, L.attn_norm, d.norm_eps, k.tn, hd, nullptr, xn,
+                                          pending ? h : nullptr, a8 ? R.xq : nullptr, a8 ? R.sx : nullptr, pending ? &R.sl_part2 : nullptr));
         R.sl_part2 = SplitSlabs{};
         prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
         { int rc = layer_linear(c, rank, L.wqkv, xn, k.tn, R.qkv + k.t0 * nqkv, L.wqkv.N, false, a8, &R.sl_qkv); if (rc) return rc; }
@@ -1313,7 +1409,7 @@ static int layer_attention_part(pplhip_ctx* c, int rank, int l, const Chunk& k, 
 }
 
 // feed-forward block of layer l for one chunk: SkipRMSNorm -> w13 with fused SwiGLU (K3 + K10) -> w2 (partial sums)
-static int layer_ffn_part(pplhip_ctx* c, int rank, int l, const Chunk& k) {
+static int layer_ffn_part(pplhip_ctx* c, int rank, int l, const Chunk& k, bool xn_ready = false) {
     Rank& R = c->ranks[rank];
     const pplhip_model_desc& d = c->d;
     hipStream_t s = R.stream;
@@ -1324,8 +1420,9 @@ static int layer_ffn_part(pplhip_ctx* c, int rank, int l, const Chunk& k) {
     uint16_t* xn = R.xn + k.t0 * hd;
     uint16_t* act = R.act + k.t0 * (int64_t)L.w2.Kp;
     const bool a8 = d.act_quant_bit == 8;
-    HIPCK(c, rank, launch_rmsnorm(s, h, R.part + k.t0 * hd, L.ffn_norm, d.norm_eps, k.tn, hd, nullptr, xn, h, a8 ? R.xq : nullptr,
-                                  a8 ? R.sx : nullptr, &R.sl_part));
+    if (!xn_ready)
+        HIPCK(c, rank, launch_rmsnorm(s, h, R.part + k.t0 * hd, L.ffn_norm, d.norm_eps, k.tn, hd, nullptr, xn, h, a8 ? R.xq : nullptr,
+                                      a8 ? R.sx : nullptr, &R.sl_part));
     R.sl_part = SplitSlabs{};
     prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
     { int rc = layer_linear(c, rank, L.w13, xn, k.tn, act, L.w2.Kp, /*swiglu=*/true, a8); if (rc) return rc; }
@@ -1336,13 +1433,39 @@ static int layer_ffn_part(pplhip_ctx* c, int rank, int l, const Chunk& k) {
     return 0;
 }
 
+// the sequence-parallel residual stream is in force for this rank's steps (pplhip_ctx::fuse_norm_want)
+static bool fuse_norm_active(const pplhip_ctx* c, const Rank& R) {
+    const int hd = c->d.hidden_dim;
+    return c->fuse_norm_want && c->tp_on && c->tp > 1 && c->d.act_quant_bit != 8 && !R.dump_dev && hd % 8 == 0 && hd <= P2P_NORM_MAX_HIDDEN &&
+           (c->comm_mode == 2 || c->emulate_tp);
+}
+
 // all-reduce(sum) of the chunk's rows of `buf` ([T, hidden] fp16).  Overlapped mode: on the communication stream,
 // after the compute stream's work so far; the compute stream picks the result up through R.ev_comm[ci] later.
-static int chunk_allreduce(pplhip_ctx* c, int rank, uint16_t* buf, const Chunk& k, int ci, bool overlapped) {
+// norm_w != NULL (fuse_norm_active): the collective also folds the reduced rows into the residual stream and normalises them with norm_w --
+// afterwards R.xn holds rmsnorm(h + sum) * norm_w for every row of the chunk and R.h the new residual on the rows this rank owns.
+static int chunk_allreduce(pplhip_ctx* c, int rank, uint16_t* buf, const Chunk& k, int ci, bool overlapped, const uint16_t* norm_w = nullptr) {
     Rank& R = c->ranks[rank];
     const int hd = c->d.hidden_dim;
     uint16_t* p = buf + k.t0 * hd;
     auto reduce_on = [&](hipStream_t st) -> int {
+        if (norm_w && c->comm_mode == 2) {
+            const bool ch1 = R.channel == 1;
+            HIPCK(c, rank, launch_p2p_allreduce_norm(st, R.peers, R.global_rank, c->tp, (size_t)((char*)p - R.xbase),
+                                                     ch1 ? R.x_scratch2[R.ar_count2++ & 1] : R.x_scratch[R.ar_count++ & 1], k.tn, hd, R.h + k.t0 * hd, norm_w,
+                                                     c->d.norm_eps, R.xn + k.t0 * hd, ch1 ? ++R.p2p_epoch2 : ++R.p2p_epoch, c->p2p_timeout_ticks, R.p2p_status,
+                                                     ch1 ? 1 : 0));
+            return 0;
+        }
+        if (norm_w) {
+            // one rank's slice without its peers (bench.py --emulate-tp): the link part of the collective is skipped as before; what stays is
+            // the rank's OWN share of the fused kernel's arithmetic -- residual add + norm of the rows it owns (the other rows of xn keep
+            // whatever they held: the emulated step's values are meaningless anyway, its timing is the point)
+            const int64_t per = (k.tn + c->tp - 1) / c->tp, lo = std::min<int64_t>(per * R.global_rank, k.tn), nown = std::min<int64_t>(per, k.tn - lo);
+            uint16_t* h = R.h + (k.t0 + lo) * hd;
+            if (nown > 0) HIPCK(c, rank, launch_rmsnorm(st, h, p + lo * hd, norm_w, c->d.norm_eps, nown, hd, nullptr, R.xn + (k.t0 + lo) * hd, h));
+            return 0;
+        }
         if (c->comm_mode == 2) {
             if (R.channel == 1)
                 HIPCK(c, rank, launch_p2p_allreduce(st, R.peers, R.global_rank, c->tp, (size_t)((char*)p - R.xbase), R.x_scratch2[R.ar_count2++ & 1],
@@ -1475,6 +1598,7 @@ static int run_launches(pplhip_ctx* c, int rank) {
     int split[2] = {1, 1};
     for (int i = 0; i < nck; ++i) split[i] = ck[i].nd > 0 ? decode_split(c, ck[i].nd, R.max_kv_len) : 1;
 
+    const bool fuse = fuse_norm_active(c, R);
     static const int defer_on = getenv("PPLHIP_DEFER_REDUCE") ? atoi(getenv("PPLHIP_DEFER_REDUCE")) : 1;
     R.defer_reduce = defer_on && !comm && d.act_quant_bit != 8 && !R.dump_dev && (nck == 1 || dual);
     R.defer_qkv = defer_on && d.act_quant_bit != 8 && !R.dump_dev && (nck == 1 || dual);   // (wo / w2 feed the all-reduce: their slabs are summed first)
@@ -1497,18 +1621,19 @@ static int run_launches(pplhip_ctx* c, int rank) {
         for (int i = 0; i < nck; ++i) {
             if (ov && l > 0 && !tpdbg2 && (rc = wait_reduced(c, rank, i))) return rc;  // part2 rows of chunk i are reduced
             if (dual && i == 1) { enter2(); g2.in = true; }
-            if ((rc = layer_attention_part(c, rank, l, ck[i], pending, split[i], threads))) return rc;
-            if (comm && (rc = chunk_allreduce(c, rank, R.part, ck[i], i, ov))) return rc;
+            if ((rc = layer_attention_part(c, rank, l, ck[i], pending, split[i], threads, fuse && l > 0))) return rc;
+            if (comm && (rc = chunk_allreduce(c, rank, R.part, ck[i], i, ov, fuse ? R.layers[l].ffn_norm : nullptr))) return rc;
             if (g2.in) { leave2(); g2.in = false; }
         }
         for (int i = 0; i < nck; ++i) {
             if (ov && !tpdbg2 && (rc = wait_reduced(c, rank, i))) return rc;            // part rows of chunk i are reduced
             if (dual && i == 1) { enter2(); g2.in = true; }
-            if ((rc = layer_ffn_part(c, rank, l, ck[i]))) return rc;
-            if (comm && (rc = chunk_allreduce(c, rank, R.part2, ck[i], i, ov))) return rc;
+            if ((rc = layer_ffn_part(c, rank, l, ck[i], fuse))) return rc;
+            // (fused: the collective behind w2 normalises for the NEXT consumer -- the next layer's attention norm, or the final norm)
+            if (comm && (rc = chunk_allreduce(c, rank, R.part2, ck[i], i, ov, !fuse ? nullptr : (l + 1 < d.num_layers ? R.layers[l + 1].attn_norm : R.norm)))) return rc;
             if (g2.in) { leave2(); g2.in = false; }
         }
-        pending = R.part2;
+        pending = fuse ? nullptr : R.part2;
         if (R.dump_dev) {
             if (ov && !tpdbg2) for (int i = 0; i < nck; ++i) if ((rc = wait_reduced(c, rank, i))) return rc;
             HIPCK(c, rank, hipMemcpyAsync(R.dump_dev + (size_t)(l + 1) * 2 * dump_n, R.h, dump_n * 2, hipMemcpyDeviceToDevice, s));
@@ -1523,15 +1648,23 @@ static int run_launches(pplhip_ctx* c, int rank) {
     }
     // K11: last-token gather + final (Skip)RMSNorm (the last FFN output is folded into the residual of the gathered
     // rows only) + lm_head (+ all-gather of the vocab shards)
-    HIPCK(c, rank, launch_rmsnorm(s, R.h, pending, R.norm, d.norm_eps, B, hd, R.d_seq, R.hn, nullptr, nullptr, nullptr, pending ? &R.sl_part2 : nullptr));
+    const uint16_t* hn = R.hn;
+    if (fuse && d.num_layers > 0) {
+        // the last collective already applied the final norm to every row: only the last-token gather is left (a pure-decode step's rows
+        // ARE the last tokens, in order)
+        if (T == B) hn = R.xn;
+        else HIPCK(c, rank, launch_gather_last_rows(s, R.xn, R.d_seq, B, hd, R.hn));
+    } else {
+        HIPCK(c, rank, launch_rmsnorm(s, R.h, pending, R.norm, d.norm_eps, B, hd, R.d_seq, R.hn, nullptr, nullptr, nullptr, pending ? &R.sl_part2 : nullptr));
+    }
     R.sl_part2 = SplitSlabs{};
     prof_begin(c, R, PPLHIP_PROF_GEMM, &ev);
     if (!comm) {
-        HIPCK(c, rank, launch_linear(s, R.hn, R.output.w, nullptr, 0, 0, B, R.output.N, hd, R.logits, d.vocab_size, true, R.gemm_ws, R.gemm_ws_bytes));
+        HIPCK(c, rank, launch_linear(s, hn, R.output.w, nullptr, 0, 0, B, R.output.N, hd, R.logits, d.vocab_size, true, R.gemm_ws, R.gemm_ws_bytes));
         prof_end(R, &ev);
     } else {
         const int vl = c->vocab_local;
-        HIPCK(c, rank, launch_linear(s, R.hn, R.output.w, nullptr, 0, 0, B, vl, hd, R.logits_local, vl, true, R.gemm_ws, R.gemm_ws_bytes));
+        HIPCK(c, rank, launch_linear(s, hn, R.output.w, nullptr, 0, 0, B, vl, hd, R.logits_local, vl, true, R.gemm_ws, R.gemm_ws_bytes));
         prof_end(R, &ev);
         // every collective of this communicator is issued on ONE stream (the communication stream when overlapping)
         hipStream_t cs = (ov && !tpdbg2) ? R.comm_stream : s;
@@ -1636,7 +1769,9 @@ int pplhip_comm_info(pplhip_ctx* c, int64_t rows, pplhip_comm_info_t* out) {
 }
 
 // one all-reduce of fp16 [rows, hidden], `iters` times back to back on the rank's stream, between two events.  Collective: every rank
-// of the group calls it with the same arguments.  path 0: the collectives in use; 1: RCCL (when a communicator exists)
+// of the group calls it with the same arguments.  path 0: the collectives in use; 1: RCCL (when a communicator exists).
+// The call enqueues AND synchronises: a context that holds several local ranks must call it from one thread per rank at the same time (like
+// pplhip_run under ParallelExecute) -- rank by rank from one thread would wait for peers that were never enqueued.
 int pplhip_comm_allreduce_us(pplhip_ctx* c, int rank, int64_t rows, int32_t iters, int32_t path, float* us) {
     if (!c || rank < 0 || rank >= (int)c->ranks.size() || !us || iters < 1 || rows < 1) return PPLHIP_INVALID_VALUE;
     Rank& R = c->ranks[rank];
@@ -1645,22 +1780,24 @@ int pplhip_comm_allreduce_us(pplhip_ctx* c, int rank, int64_t rows, int32_t iter
     if (path == 1 && !R.comm) return 0;              // no RCCL communicator: nothing to compare with
     if (path == 0 && c->comm_mode != 2 && !R.comm) return 0;
     HIPCK(c, rank, hipSetDevice(R.device));
-    hipEvent_t e0, e1;
-    HIPCK(c, rank, hipEventCreate(&e0));
-    HIPCK(c, rank, hipEventCreate(&e1));
+    struct Ev {   // destroyed on every return path
+        hipEvent_t e = nullptr;
+        ~Ev() { if (e) (void)hipEventDestroy(e); }
+    } ev0, ev1;
+    HIPCK(c, rank, hipEventCreate(&ev0.e));
+    HIPCK(c, rank, hipEventCreate(&ev1.e));
+    hipEvent_t e0 = ev0.e, e1 = ev1.e;
     const int hd = c->d.hidden_dim;
     const Chunk k{0, rows, 0, rows, rows};
     for (int it = -2; it < iters; ++it) {            // two warm-up rounds
         if (it == 0) HIPCK(c, rank, hipEventRecord(e0, R.stream));
         if (path == 1) NCCLCK(c, rank, ncclAllReduce(R.part, R.part, (size_t)rows * hd, ncclFloat16, ncclSum, R.comm, R.stream));
-        else if (int rc = chunk_allreduce(c, rank, R.part, k, 0, false)) return rc;
+        else if (int rc = chunk_allreduce(c, rank, R.part, k, 0, false, fuse_norm_active(c, R) ? R.norm : nullptr)) return rc;   // what a step issues
     }
     HIPCK(c, rank, hipEventRecord(e1, R.stream));
     HIPCK(c, rank, hipStreamSynchronize(R.stream));
     float ms = 0.f;
     HIPCK(c, rank, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     *us = ms * 1e3f / (float)iters;
     if (R.p2p_status && *R.p2p_status) return fail(c, rank, PPLHIP_DEVICE_RUNTIME_ERROR, "a direct collective timed out during pplhip_comm_allreduce_us");
     return 0;

@@ -81,7 +81,7 @@ class CommInfo(C.Structure):
 # every symbol include/pplhip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "pplhip_version", "pplhip_device_count", "pplhip_get_unique_id", "pplhip_init", "pplhip_destroy",
-    "pplhip_comm_export", "pplhip_comm_connect", "pplhip_comm_mode", "pplhip_comm_info", "pplhip_comm_allreduce_us",
+    "pplhip_comm_export", "pplhip_comm_connect", "pplhip_comm_mode", "pplhip_comm_fused_norm", "pplhip_comm_info", "pplhip_comm_allreduce_us",
     "pplhip_last_error", "pplhip_rank_load", "pplhip_rank_set_tensor", "pplhip_rank_init_synthetic", "pplhip_rank_tie_output",
     "pplhip_kv_block_bytes", "pplhip_kv_capacity", "pplhip_kv_alloc", "pplhip_kv_ptrs", "pplhip_kv_read",
     "pplhip_kv_write", "pplhip_kv_fill_synthetic", "pplhip_set_inputs", "pplhip_run", "pplhip_debug_run_dump", "pplhip_logits", "pplhip_copy_logits", "pplhip_sync",
@@ -112,6 +112,7 @@ def lib():
         L.pplhip_comm_export.argtypes = [vp, C.c_int, vp]
         L.pplhip_comm_connect.argtypes = [vp, vp]
         L.pplhip_comm_mode.argtypes = [vp]
+        L.pplhip_comm_fused_norm.argtypes = [vp]
         L.pplhip_comm_info.argtypes = [vp, i64, C.POINTER(CommInfo)]
         L.pplhip_comm_allreduce_us.argtypes = [vp, C.c_int, i64, i32, i32, C.POINTER(f32)]
         L.pplhip_rank_load.argtypes = [vp, C.c_int, C.c_char_p]
@@ -257,7 +258,10 @@ class Context:
         """what a multi-GPU run does at a pure-decode step of `rows` rows: mode, self-test verdict, schedule, fallbacks taken"""
         ci = CommInfo()
         self._ck(lib().pplhip_comm_info(self.h, rows, C.byref(ci)), -1, "comm_info")
-        return {"mode": COMM_MODES[ci.mode], "selftest": {0: "not run", 1: "passed", -1: "failed"}[ci.selftest],
+        mode = COMM_MODES[ci.mode]
+        if lib().pplhip_comm_fused_norm(self.h) == 1:
+            mode += " + residual add and RMSNorm fused between the two shots (sequence-parallel residual stream)"
+        return {"mode": mode, "selftest": {0: "not run", 1: "passed", -1: "failed"}[ci.selftest],
                 "schedule": COMM_SCHEDULES[ci.schedule], "rccl_communicator": bool(ci.has_rccl),
                 "two_stream_rows": [int(ci.dual_min_rows), int(ci.dual_max_rows)], "fallbacks": ci.notes.decode(errors="replace")}
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times pplhip_op_linear on the four linear shapes of a LLaMA-2-7B layer at M = 1024 (W8A16) with HIP events.
-usage: python profiles/gemm_microbench.py [M] [wq 8|4|0] [7b|7b-tp8|13b-tp2|70b-tp8] [only this shape: wqkv|wo|w13|w2]"""
+usage: python profiles/gemm_microbench.py [M] [wq 8|4|0] [7b|7b-tp2|7b-tp4|7b-tp8|13b-tp2|70b-tp8] [only this shape: wqkv|wo|w13|w2]"""
 import os, sys
 import numpy as np
 import torch
@@ -12,6 +12,8 @@ WQ = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 MODEL = sys.argv[3] if len(sys.argv) > 3 else "7b"
 SHAPES = {
     "7b": [("wqkv", 12288, 4096), ("wo", 4096, 4096), ("w13", 22016, 4096), ("w2", 4096, 11008)],
+    "7b-tp2": [("wqkv", 6144, 4096), ("wo", 4096, 2048), ("w13", 11008, 4096), ("w2", 4096, 5504)],
+    "7b-tp4": [("wqkv", 3072, 4096), ("wo", 4096, 1024), ("w13", 5504, 4096), ("w2", 4096, 2752)],
     "7b-tp8": [("wqkv", 1536, 4096), ("wo", 4096, 512), ("w13", 2752, 4096), ("w2", 4096, 1408)],
     "13b-tp2": [("wqkv", 7680, 5120), ("wo", 5120, 2560), ("w13", 13824, 5120), ("w2", 5120, 6912)],
     "70b-tp8": [("wqkv", 1280, 8192), ("wo", 8192, 1024), ("w13", 7168, 8192), ("w2", 8192, 3584)],

@@ -4,9 +4,12 @@ operands) reaches on the layer shapes of LLaMA-2-7B at the batch sizes of the be
 product calls a library GEMM.  usage: python profiles/hipblaslt_reference.py"""
 import torch
 SHAPES = [("wqkv", 12288, 4096), ("wo", 4096, 4096), ("w13", 22016, 4096), ("w2", 4096, 11008)]
-for M in (1024, 8192):
+TP4 = [("wqkv", 3072, 4096), ("wo", 4096, 1024), ("w13", 5504, 4096), ("w2", 4096, 2752)]   # one rank's slice at tensor-parallel 4 / 8 (round 6)
+TP8 = [("wqkv", 1536, 4096), ("wo", 4096, 512), ("w13", 2752, 4096), ("w2", 4096, 1408)]
+for M, shapes, label in ((1024, SHAPES, "7b"), (8192, SHAPES, "7b"), (1024, TP4, "7b-tp4"), (1024, TP8, "7b-tp8")):
     tot_t = tot_f = 0.0
-    for name, N, K in SHAPES:
+    print(f"# {label} M={M}")
+    for name, N, K in shapes:
         a = torch.randn(M, K, device="cuda", dtype=torch.float16)
         b = torch.randn(N, K, device="cuda", dtype=torch.float16)
         for _ in range(3):

@@ -10,10 +10,14 @@ geometry, W8A16, int8-g8 KV on shuffled 16-token pages.  The same 8192-token pro
 two correct fp16 evaluation orders (profiles/r04_prefix_cache_benchmark.log: 13 of 64 synthetic requests answered differently after a
 cache hit), so "equal" would be a coin toss.  As in tests/test_gpu_fulldepth.py the lm_head rows of a CHOSEN continuation are therefore
 engineered from the final hidden states of a teacher-forced run so that every chosen token wins its row by a wide margin; both paths must
-then produce exactly the chosen tokens, and the fraction of rows whose realised margin exceeds twice the cold-vs-cached logits distance is
-asserted.  The oracle cannot run this size in test time (8192 tokens x 32 layers of 7B on CPU: minutes); the cache-
-prefill step is held against the oracle at 2 layers in tests/test_gpu_config34_shape.py and the cold path at 32 layers in
-tests/test_gpu_fulldepth.py."""
+then produce exactly the chosen tokens.
+
+What this test is and is not: cold prefill and the partial-hit cache-prefill are BIT-IDENTICAL on the device --
+both read K / V back from the slab through the same kernel on the same 16-token-aligned tiles -- so the logits distance between the two
+paths is asserted to be exactly 0: a PROPERTY of the design (a prefix-cache hit cannot change an answer), stronger than any margin
+fraction, and not a parity claim.  Parity of these paths against the ORACLE at 32 layers is in tests/test_gpu_fulldepth.py (cache-prefill
+behind cached pages; a full hit's single row through the decode kernel and through the cache-prefill kernel), at this size with 2 layers
+in tests/test_gpu_config34_shape.py; the oracle cannot run 8192 tokens x 32 layers of 7B in test time."""
 import numpy as np
 import pytest
 
@@ -94,11 +98,11 @@ def test_cold_prefill_and_prefix_cache_hit_emit_the_same_tokens_at_32_layers():
         margin = srt[:, -1] - srt[:, -2]
         safe = margin > 2 * dist
         lscale = max(1.0, float(np.abs(l_cold).max()))
-        record_err("config5_cold_vs_prefix_hit_logits_32_layers", dist / lscale, 4e-2,
+        record_err("config5_cold_vs_prefix_hit_logits_32_layers_bit_identical", dist / lscale, 0.0,
                    noise=float(np.abs(y_cold - y_hit).max() / max(1.0, np.abs(y_cold).max())))
         assert (t_cold == chosen).all(), (t_cold, chosen)
         assert (t_hit == chosen).all(), (t_hit, chosen)                  # the prefix-cache hit answers token for token like the cold request
-        assert safe.mean() >= MIN_SAFE_FRACTION, (safe.mean(), margin / lscale, dist / lscale)
-        assert dist <= 4e-2 * lscale, dist / lscale                      # two device paths at 32 layers: the distance of tests/test_gpu_fulldepth.py's noise floor (1.3e-2) x 3
+        assert dist == 0.0, dist / lscale                                # ... because it computes the same bits (see the docstring)
+        assert (margin > 0).all() and safe.mean() >= MIN_SAFE_FRACTION
     finally:
         ctx.close()

@@ -247,3 +247,114 @@ def test_7b_prefill_and_decode_paths_both_match_the_oracle():
     finally:
         ctx.close()
         rm.close()
+
+
+def _paged_pair(m, page=16, kv_tokens=1024):
+    desc = ref.make_desc(max_position=2048, cache_quant_bit=8, cache_quant_group=8, cache_layout=3, cache_mode=1, page_size=page,
+                         weight_quant_bit=8, weight_quant_group=128, **DIMS)
+    rm = ref.RefModel(desc)
+    rm.init_synthetic(SEED)
+    ctx = m.Context(m.copy_desc(desc), max_running_batch=8, max_tokens_per_step=256)
+    ctx.init_synthetic(0, SEED)
+    ctx.kv_alloc(0, kv_tokens)
+    return desc, rm, ctx
+
+
+def _three_orders(rm, kv_tokens, steps):
+    """the LAST step's logits of a sequence of oracle steps, in the specification's order and two other summation orders (each on a
+    fresh slab): [spec, alt, alt2] and the noise floor = the largest pairwise distance"""
+    outs = []
+    for md in (None, ref.MODE_ALT_ORDER, ref.MODE_ALT_ORDER2):
+        def run():
+            rm.kv_alloc(kv_tokens)
+            o = None
+            for st in steps:
+                o = ref.forward([rm], ref.make_step(*st))
+            return o
+        if md is None:
+            outs.append(run())
+        else:
+            with ref.mode(md):
+                outs.append(run())
+    noise = max(_rel(outs[1], outs[0]), _rel(outs[2], outs[0]), _rel(outs[2], outs[1]))
+    return outs, noise
+
+
+def test_7b_cache_prefill_behind_cached_pages_vs_oracle_32_layers():
+    """Config 5's cache-prefill step against the ORACLE at full depth (weak item 3: the 32-layer evidence of
+    tests/test_gpu_config5_tokens.py compares the device with itself).  W8A16, int8-g8 KV on SHUFFLED 16-token pages: 96 tokens are
+    prefilled cold (the cached prefix: 6 pages), then the remaining 35 tokens run as a cache-prefill step at start_pos 96
+    (/root/reference/src/engine/llm_engine.cc:114, /root/reference/src/generator/llm_generator.cc:233-241) on pages of their own.  Each
+    side fills its own cache (no slab copied across).  Bar: 1.3 x the noise floor measured on the same two steps with three summation
+    orders of the oracle -- the frozen full-depth ratio; the oracle's cold prefill of all 131 tokens gives the same bits (it always reads
+    K / V back from the slab), asserted."""
+    m = load_pplhip()
+    desc, rm, ctx = _paged_pair(m)
+    try:
+        rng = np.random.RandomState(23)
+        prompt = rng.randint(3, DIMS["vocab_size"], size=131).astype(np.int64)
+        npg = 9                                                                     # ceil(131 / 16)
+        pages = rng.permutation(KV_TOKENS // 16)[:npg].reshape(1, npg).astype(np.int64)
+        steps = [(prompt[:96], [0, 96], [0], pages, 0, npg), (prompt[96:], [0, 35], [96], pages, 0, npg)]
+        (want, alt, alt2), noise = _three_orders(rm, KV_TOKENS, steps)
+        rm.kv_alloc(KV_TOKENS)
+        cold = ref.forward([rm], ref.make_step(prompt, [0, 131], [0], pages, 0, npg))
+        assert (cold == want).all()                                                  # the oracle: one computation either way
+        ctx.set_inputs(0, m.make_step(*steps[0]))
+        ctx.run(0)
+        ctx.set_inputs(0, m.make_step(*steps[1]))
+        ctx.run(0, cache_prefill=1)
+        got = ctx.copy_logits(1)
+        err = _rel(got, want)
+        record_err("fulldepth_cache_prefill_35_behind_96_cached_paged_vs_oracle", err, RATIO_NOISE_LOGITS * noise, noise=noise)
+        assert err <= RATIO_NOISE_LOGITS * noise, (err, noise)
+        # the int8 K / V bytes both steps wrote: layer 0's (cache layout 3 = [L, 2, h, N, d]: the first 2 h N d bytes) see inputs that are
+        # equal on both sides up to one RMSNorm + GEMM -- a few LSB on few bytes; deeper layers inherit the residual stream's drift
+        # (the logits bound above is what holds them), so there only the fraction of differing bytes is recorded
+        gk, rk = ctx.kv_read(0, 0), rm.kv_array(0)
+        n0 = 2 * DIMS["num_kv_heads"] * KV_TOKENS * (DIMS["hidden_dim"] // DIMS["num_heads"])
+        assert (np.abs(gk[:n0].astype(np.int32) - rk[:n0].astype(np.int32)) <= 3).all()
+        assert (gk[:n0] != rk[:n0]).mean() < 0.01
+        record_err("fulldepth_cache_prefill_kv_bytes_differing_fraction_all_layers", float((gk != rk).mean()), 1.0)
+    finally:
+        ctx.close()
+        rm.close()
+
+
+@pytest.mark.parametrize("as_decode_row", [True, False])
+def test_7b_full_prefix_hit_single_row_vs_oracle_32_layers(as_decode_row):
+    """A FULL prefix-cache hit at full depth: every page of the 128-token prompt is cached, so the generator re-runs only the last token at
+    start_pos = len - 1 (/root/reference/src/generator/llm_generator.cc:233-236) -- ONE row over 127 cached keys + itself.  The row goes
+    through the decode-attention kernel when the step counts it as a decoding request, through the cache-prefill kernel (one query row)
+    otherwise; both are held against the oracle's logits of the same step AND against the cold prefill's last row, inside 1.3 x the
+    oracle's noise floor on the same steps (three summation orders)."""
+    m = load_pplhip()
+    desc, rm, ctx = _paged_pair(m)
+    try:
+        rng = np.random.RandomState(29)
+        n = 128
+        prompt = rng.randint(3, DIMS["vocab_size"], size=n).astype(np.int64)
+        npg = n // 16
+        pages = rng.permutation(KV_TOKENS // 16)[:npg].reshape(1, npg).astype(np.int64)
+        dec = 1 if as_decode_row else 0
+        steps = [(prompt, [0, n], [0], pages, 0, npg), (prompt[-1:], [0, 1], [n - 1], pages, dec, npg)]
+        (want, alt, alt2), noise = _three_orders(rm, KV_TOKENS, steps)
+        rm.kv_alloc(KV_TOKENS)
+        cold = ref.forward([rm], ref.make_step(*steps[0]))
+        assert (cold == want).all()                                                  # oracle: the hit row recomputes the same bits
+        ctx.set_inputs(0, m.make_step(*steps[0]))
+        ctx.run(0)
+        got_cold = ctx.copy_logits(1).copy()
+        ctx.set_inputs(0, m.make_step(*steps[1]))
+        ctx.run(0, cache_prefill=0 if as_decode_row else 1)
+        got = ctx.copy_logits(1)
+        tag = "decode_kernel" if as_decode_row else "cache_prefill_kernel"
+        e_hit, e_cold, e_dev = _rel(got, want), _rel(got_cold, want), _rel(got, got_cold)
+        record_err(f"fulldepth_full_prefix_hit_row_{tag}_vs_oracle", e_hit, RATIO_NOISE_LOGITS * noise, noise=noise)
+        record_err(f"fulldepth_full_prefix_hit_row_{tag}_vs_device_cold_prefill", e_dev, 2 * noise, noise=noise)
+        assert e_cold <= RATIO_NOISE_LOGITS * noise, (e_cold, noise)
+        assert e_hit <= RATIO_NOISE_LOGITS * noise, (e_hit, noise)
+        assert e_dev <= 2 * noise, (e_dev, noise)                                    # two device paths: two more samples of the same noise
+    finally:
+        ctx.close()
+        rm.close()

@@ -166,3 +166,32 @@ def test_bench_self_launches_without_a_launcher():
     assert len(line) == 1
     res = json.loads(line[0])
     assert res["n_gpus"] == 2 and res["dry_run"] is True and res["unique_id_agreed"] is True
+
+
+def test_bench_rank_that_dies_before_the_handle_exchange_gives_one_error_line():
+    """a peer that never reaches the IPC-handle exchange must not hang the driver.  Two bench.py processes WITHOUT the
+    elastic launcher (nothing tears the survivor down from outside); rank 1 exits right before the exchange.  Rank 0 must exit non-zero
+    within the start-up guard's limit, with exactly ONE JSON line that carries "error", the phase it was waiting in and the collectives'
+    fallback notes; rank 1's exit code is the hook's."""
+    import socket, time
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    base.update(OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run", "--dry-run-fail-rank", "1",
+           "--startup-timeout", "45"]
+    t0 = time.time()
+    procs = [subprocess.Popen(cmd, env=dict(base, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(2)]
+    out0, err0 = procs[0].communicate(timeout=300)
+    procs[1].communicate(timeout=60)
+    assert time.time() - t0 < 200
+    assert procs[1].returncode == 17
+    assert procs[0].returncode not in (0, None)
+    lines = [l for l in out0.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out0.decode() + err0.decode()
+    res = json.loads(lines[0])
+    assert "error" in res and res["value"] == 0.0 and res["n_gpus"] == 2
+    assert res["phase"] == "IPC-handle exchange"
+    assert "fallbacks" in res["collectives"]
+    assert sum(1 for l in err0.decode().splitlines() if l.startswith("[bench] rank 0:")) == 1   # one diagnostic line
