@@ -714,19 +714,15 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
     static const int wide = tune_int("PPLHIP_GEMM_WIDE", 1);
     if (wide && wq_bit == 8 && K % G_BK == 0 && M >= 512 && (M < 4096 || wide == 2) && N >= 8192) {
         const int nc = wide == 2 ? 12 : linear_w8_wide_waves(M, N);  // (2: experiments -- every eligible shape, any M)
-        // PPLHIP_GEMM_ASM=1: the same block tile on the hand-scheduled K loop of k_gemm_asm.hip (round 4).  Equal speed on random
-        // operands -- both kernels sit on the chip's power limit, profiles/r04_gemm_asm_experiments.md -- so it is not the default
-        static const int asm_loop = getenv("PPLHIP_GEMM_ASM") ? atoi(getenv("PPLHIP_GEMM_ASM")) : 0;
-        if (nc && asm_loop) return launch_linear_w8_asm(s, x, (const int8_t*)w, scale, M, N, K, y, ldy, epi);
+        // (round 4's hand-scheduled K loop for this block tile -- equal speed, both on the chip's power limit -- lives under profiles/probes/gemm_asm/ since round 6)
         if (nc) return launch_linear_w8_wide(s, x, (const int8_t*)w, scale, M, N, K, y, ldy, epi, nc);
     }
-    // W8A16 slices of a tensor-parallel step (512 <= M <= 1024) whose 128 x 128 tiles leave a quarter of the CUs idle or need K slabs, while
-    // 128 x 96 / 64 x 96 tiles fill one round of 256 blocks: the k-split kernel of k_gemm_ks.hip (7B at tensor-parallel 8: wqkv, w13; at 4: wqkv)
-    if (wq_bit == 8 && epi != EPI_F32 && !force_generic && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)scale & 7) == 0 &&
-        ((uintptr_t)y & 7) == 0) {
-        const int tile = linear_w8_ks_tile(M, N, K);
-        if (tile) return launch_linear_w8_ks(s, x, (const int8_t*)w, scale, M, N, K, y, ldy, epi, tile);
-    }
+    // (Round 6, measured and not adopted: 128 x 96 / 64 x 96 tiles whose four multiplying waves split each K tile by k-step on 32 x 32 x 16
+    // MFMAs -- 232 / 256 blocks instead of 176 / 96 for the 7B / TP8 slice's w13 / wqkv, 22 KiB of fragment reads per K tile instead of 72.
+    // Parity-green, and no faster: w13 35.5 against 34.9 us, the emulated TP-8 step +0.07 ms.  Its ablation builds say why -- with the MFMAs
+    // compiled out the K loop still takes 0.29 us per tile: the 22-24 KiB of LDS-DMA per K tile and CU move at ~40 B / clk whatever the tile
+    // computes, and ~9 us of every launch are dispatch, first-byte latency, the final exchange and the stores.
+    // profiles/probes/gemm_ks/, profiles/r06_tp_slice_gemm_experiments.md)
     const int n_tiles = (N + G_BN - 1) / G_BN;
     const int m_tiles = (int)((M + G_BM - 1) / G_BM);
     const int n_tiles_pad = (n_tiles + 7) / 8 * 8;

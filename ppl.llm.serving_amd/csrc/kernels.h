@@ -110,18 +110,10 @@ hipError_t launch_attn_decode_gqa(hipStream_t s, const uint16_t* qkv, const KvAd
 // W8A16 128 (m) x 384 (n) tile kernel (k_gemm_wide.hip); K % 64 == 0, N % 4 == 0; epi 0 fp16 / 1 fp32 / 2 fused SwiGLU
 hipError_t launch_linear_w8_wide(hipStream_t s, const uint16_t* x, const int8_t* w, const uint16_t* scale, int64_t M, int N, int K, void* y,
                                  int64_t ldy, int epi, int nc);
-// the same block tile with a hand-allocated, hand-scheduled K loop (k_gemm_asm.hip + gen_gemm_asm.py); same contract
-hipError_t launch_linear_w8_asm(hipStream_t s, const uint16_t* x, const int8_t* w, const uint16_t* scale, int64_t M, int N, int K, void* y,
-                                int64_t ldy, int epi);
 // W4A16 (group 128) on 128 (m) x 64 (n) tiles, no K slabs (k_gemm_pc.hip): a few hundred rows; epi 0 fp16 / 2 fused SwiGLU
 bool linear_w4_pc_supported(int group, int64_t M, int N, int K, const void* x, const void* w, const void* scale, const void* y, int64_t ldy, int epi);
 hipError_t launch_linear_w4_pc(hipStream_t s, const uint16_t* x, const void* w, const uint16_t* scale, int64_t M, int N, int K, void* y,
                                int64_t ldy, int epi);
-// W8A16 on k-split tiles (k_gemm_ks.hip): the per-rank slices of a tensor-parallel decode step whose 128 x 128 tiles would leave CUs idle.
-// linear_w8_ks_tile: 0 none, 1 128 (m) x 96 (n), 2 64 x 96; epi 0 fp16 / 2 fused SwiGLU
-int linear_w8_ks_tile(int64_t M, int N, int K);
-hipError_t launch_linear_w8_ks(hipStream_t s, const uint16_t* x, const int8_t* w, const uint16_t* scale, int64_t M, int N, int K, void* y,
-                               int64_t ldy, int epi, int tile);
 int linear_w8_wide_waves(int64_t M, int N);  // 12 when the 128 x 384 tiles fill rounds of 256 blocks well enough, else 0
 hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const uint16_t* scale, int wq_bit, int group,
                          int64_t M, int N, int K, void* y, int64_t ldy, bool out_fp32, float* ws = nullptr, size_t ws_bytes = 0,

@@ -25,6 +25,9 @@ namespace pplhip {
 namespace {
 
 typedef float f16v __attribute__((ext_vector_type(16)));
+#ifndef KS_ABL   // diagnosis builds only (make EXTRA=-DKS_ABL=n; WRONG results): 1 no MFMAs, 2 no ring refills, 4 no fragment re-reads, 8 no loop barriers
+#define KS_ABL 0
+#endif
 constexpr int KS_NP = 4, KS_NC = 4;   // producer waves, multiplying waves (= k-steps of a 64-deep K tile)
 
 template <int EPI, int MI, int NI, int ST>
@@ -104,8 +107,8 @@ __global__ __launch_bounds__((KS_NC + KS_NP) * 64) void gemm_w8_ks_kernel(const 
             if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PP) : "memory");
             else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (t + ST < ktiles) KS_PRODUCE(t + ST, stn);
+            if (!(KS_ABL & 8)) __syncthreads();
+            if (t + ST < ktiles && !(KS_ABL & 2)) KS_PRODUCE(t + ST, stn);
             stn = stn == ST - 1 ? 0 : stn + 1;
         }
 #undef KS_PRODUCE
@@ -134,7 +137,7 @@ __global__ __launch_bounds__((KS_NC + KS_NP) * 64) void gemm_w8_ks_kernel(const 
     for (int i = 0; i < NI; ++i) wa[i] = cvt_i8x8_f16(*reinterpret_cast<const uint2*>(Wq0 + i * 2048 + woff));
     int st = 1 % ST;   // stage of tile t + 1
     for (int t = 0; t < ktiles; ++t) {
-        __syncthreads();   // tile t + 1 is published (behind the last tile the reads below fetch a stale stage and the result is dropped: a
+        if (!(KS_ABL & 8)) __syncthreads();   // tile t + 1 is published (behind the last tile the reads below fetch a stale stage and the result is dropped: a
                            // branch here would make hipcc wait for the reads in front of the MFMAs, at the block join)
         const char* xs = Xs0 + st * XB + xoff;
         const char* ws = Wq0 + st * WB + woff;
@@ -144,13 +147,16 @@ __global__ __launch_bounds__((KS_NC + KS_NP) * 64) void gemm_w8_ks_kernel(const 
         // order is pinned (sched_group_barrier): left alone, hipcc sinks every read to just in front of its first use in the next iteration
         // and the wave waits out the LDS latency there, with no other multiplying wave on its SIMD to fill the gap.
 #pragma unroll
-        for (int i = 0; i < NI; ++i) wraw[i] = *reinterpret_cast<const uint2*>(ws + i * 2048);
+        for (int i = 0; i < NI; ++i) if (!(KS_ABL & 4) || t == 0) wraw[i] = *reinterpret_cast<const uint2*>(ws + i * 2048);
         __builtin_amdgcn_sched_group_barrier(0x100, NI, 0);          // DS reads: the raw weights
 #pragma unroll
         for (int j = 0; j < MI; ++j) {
 #pragma unroll
-            for (int i = 0; i < NI; ++i) acc[i * MI + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[i], xa[j], acc[i * MI + j], 0, 0, 0);
-            xa[j] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(xs + j * 4096));
+            for (int i = 0; i < NI; ++i) {
+                if (KS_ABL & 1) acc[i * MI + j][0] += (float)wa[i][0] * (float)xa[j][0];
+                else acc[i * MI + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[i], xa[j], acc[i * MI + j], 0, 0, 0);
+            }
+            if (!(KS_ABL & 4) || t == 0) xa[j] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(xs + j * 4096));
             __builtin_amdgcn_sched_group_barrier(0x008, NI, 0);      // NI MFMAs
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // one DS read
         }

@@ -177,21 +177,3 @@ def test_w13_gemm_with_fused_swiglu_at_batch_1024():
     record_err("config2_gemm_w13_swiglu_m1024", float(err.max()) / mag, 3e-3)
     tol = 3e-3 * np.abs(want) + 3e-3 * 0.05 * mag + 1e-5                   # two fp16 roundings upstream of the product (test_gpu_ops.py)
     assert (err <= tol).all(), (float(err.max()), mag, int((err > tol).sum()))
-
-
-def test_layer_gemms_on_the_hand_scheduled_k_loop():
-    """PPLHIP_GEMM_ASM=1 routes wqkv / w13 (the 128 x 384 block tile) through k_gemm_asm.hip, whose K loop is one generated asm statement
-    (gen_gemm_asm.py): the same parity cases as above -- wqkv with the fp16 epilogue, w13 with the fused SwiGLU, both through the LDS-staged
-    and (PPLHIP_GEMM_ASM_DIRECT_EPILOGUE) the direct epilogue -- in a child process (the switch is read once), plus a ragged shape."""
-    import os, subprocess, sys
-    code = ("import tests.test_gpu_config2_shape as t, tests.test_gpu_ops as o\n"
-            "t.test_layer_gemm_at_batch_1024('wqkv', 12288, 4096)\n"
-            "t.test_w13_gemm_with_fused_swiglu_at_batch_1024()\n"
-            "o.test_linear(8, 1000, 12000, 192)\n"
-            "o.test_linear(8, 1024, 12288, 64)\n"
-            "print('ASM-OK')\n")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra in ({}, {"PPLHIP_GEMM_ASM_DIRECT_EPILOGUE": "1"}):
-        env = dict(os.environ, PPLHIP_GEMM_ASM="1", **extra)
-        r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0 and "ASM-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
