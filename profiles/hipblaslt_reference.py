@@ -15,6 +15,12 @@ for M, shapes, label in ((1024, SHAPES, "7b"), (8192, SHAPES, "7b"), (1024, TP4,
         for _ in range(3):
             c = a @ b.t()
         torch.cuda.synchronize()
+        import time
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.1:   # the same warm-up as profiles/gemm_microbench.py
+            for _ in range(5):
+                c = a @ b.t()
+            torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(20):

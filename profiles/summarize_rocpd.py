@@ -62,11 +62,11 @@ def traffic(fetch_db, write_db, out_json, batch, kv_first, kv_last, layers, warm
     json.dump(out, open(out_json, "w"), indent=1)
 
 
-def pmc_series(db, kernel_substr, counter):
+def pmc_series(db, kernel_substr, counter, column="value"):
     cur = sqlite3.connect(db).cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)").fetchall()]
     order = "dispatch_id" if "dispatch_id" in cols else ("id" if "id" in cols else "rowid")
-    return [r[0] for r in cur.execute(f"select value from counters_collection where kernel_name like ? and counter_name = ? order by {order}",
+    return [r[0] for r in cur.execute(f"select {column} from counters_collection where kernel_name like ? and counter_name = ? order by {order}",
                                       (f"%{kernel_substr}%", counter)).fetchall()]
 
 
@@ -78,18 +78,27 @@ def traffic_table(fetch_db, write_db, out_json, model, batch, kv_len, layers, to
     import json
     batch, kv_len, layers, total_steps = map(int, (batch, kv_len, layers, total_steps))
     f, w = pmc_series(fetch_db, "attn_decode_kernel", "FETCH_SIZE"), pmc_series(write_db, "attn_decode_kernel", "WRITE_SIZE")
+    dur = pmc_series(fetch_db, "attn_decode_kernel", "FETCH_SIZE", "duration")   # ns per dispatch, of the profiled (FETCH_SIZE) pass
     n = min(len(f), len(w)) // layers
-    table = {}
+    table, dtable = {}, {}
     for i in range(min(n, total_steps)):
         fs, ws = f[i * layers:(i + 1) * layers], w[i * layers:(i + 1) * layers]
         table[str(kv_len + i + 1)] = int(2 * 1024 * sum(fs) / len(fs) + 1024 * sum(ws) / len(ws))
+        ds = dur[i * layers:(i + 1) * layers]
+        if ds:
+            dtable[str(kv_len + i + 1)] = round(sum(ds) / len(ds) / 1e3, 2)
+    used = dur[:min(n, total_steps) * layers]
     out = {"round": int(label.split()[-1]) if label.split()[-1].isdigit() else 0, "kernel": "pplhip::attn_decode_kernel<8,128>", "label": label, "model": model, "batch": batch, "kv_quant": 8,
            "cache_mode": 0, "dispatches": {"FETCH_SIZE": len(f), "WRITE_SIZE": len(w)}, "layers": layers,
-           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only; profiles/collect_r04.sh) of "
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only; profiles/collect_rNN.sh) of "
                      "`python bench.py --steps 24 --warmup 3` -- a superset of the driver's --steps 20 --warmup 5 and of the defaults",
            "source_short": f"profiles/attn_decode_traffic.json ({label}; PMC FETCH_SIZE x2 + WRITE_SIZE per dispatch, mean per kv length)",
            "correction": "gfx950: FETCH_SIZE counts a 128-B request as 64 B for wide (16 B/lane) coalesced reads, so it is doubled "
                          "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE used as is",
+           "mean_duration_us": round(sum(used) / len(used) / 1e3, 2) if used else None,
+           "mean_duration_note": "kernel duration of the same dispatches in the FETCH_SIZE pass (every launch in the table is a uniform batch launch: "
+                                 "roofline.frac can be recomputed from this file alone: algorithmic bytes / mean_duration_us)",
+           "mean_duration_us_by_kv_len": dtable,
            "hbm_bytes_per_launch_by_kv_len": table}
     json.dump(out, open(out_json, "w"), indent=1)
 
