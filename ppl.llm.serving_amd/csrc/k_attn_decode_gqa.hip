@@ -24,6 +24,7 @@
 // (profiles/r06_gqa_experiments.md): -23 % VALU per key, +13 % bandwidth at config 4's shape.
 // Grid (Hkv, requests, splits); workspace / reduce kernel shared with the multi-head kernel (k_attn_decode.hip).
 // Oracle: ref_attention (oracle/llama_ref.c).
+#include <stdlib.h>
 #include <mutex>
 #include <set>
 #include <type_traits>
@@ -38,8 +39,13 @@ namespace {
 #ifndef GQ_THREADS_N
 #define GQ_THREADS_N 512
 #endif
-constexpr int GQ_THREADS = GQ_THREADS_N;
-constexpr int GQ_WAVES = GQ_THREADS / 64;
+// waves per block: GQ_THREADS_N / 64 when a launch has fewer than GQ_SMALL_BLOCK_MIN blocks (config 4: 256 requests x 1 KV head = one 8-wave block per
+// CU), else 4 -- two blocks per CU (70 KiB of LDS each), so that one block's ramp (page ids, q, first K / V loads) and its merge run beside the
+// other's stream: short contexts in big batches are mostly ramp and merge (B 1024 x kv 512: 51 us for 21 us of traffic with 8-wave blocks)
+constexpr int GQ_WAVES_BIG = GQ_THREADS_N / 64, GQ_WAVES_SMALL = 4;
+#ifndef GQ_SMALL_BLOCK_MIN
+#define GQ_SMALL_BLOCK_MIN 512
+#endif
 #ifndef GQ_NBUF
 #define GQ_NBUF 2   // 16-key sub-tiles in flight per wave (register buffers): one PAIR (2) or two (4); round 3 measured 2 / 3 / 4 single steps at 4.46 / 4.07 / 4.16 TB/s, round 6 two pairs against one: equal at kv 2048, 10-15 % slower below (profiles/r06_gqa_nbuf_ab.log) -- issue-bound, not latency-bound
 #endif
@@ -72,15 +78,15 @@ __device__ __forceinline__ void two_product(h8 q, _Float16 s, h8& hi, h8& lo) {
     lo = __builtin_elementwise_fma(q, sv, -hi);
 }
 
-template <int QBIT, int D>
+template <int QBIT, int D, int GQ_WAVES>
 constexpr int gq_lds_bytes() {
     constexpr int nimg = (QBIT == 8 && GQ_V_EXACT) ? 2 : 1;
     constexpr int v_bytes = GQ_WAVES * 2 * nimg * (D / 16) * GQ_VSUB * 2, merge_bytes = GQ_WAVES * 16 * (D + 2) * 4;
     return v_bytes > merge_bytes ? v_bytes : merge_bytes;
 }
 
-template <int QBIT, int D, int MODE>
-__global__ __launch_bounds__(GQ_THREADS) void attn_decode_gqa_kernel(const uint16_t* __restrict__ qkv, KvAddr kv,
+template <int QBIT, int D, int MODE, int GQ_WAVES>
+__global__ __launch_bounds__(GQ_WAVES * 64) void attn_decode_gqa_kernel(const uint16_t* __restrict__ qkv, KvAddr kv,
                                                                      const int64_t* __restrict__ seq_starts,
                                                                      const int64_t* __restrict__ start_pos,
                                                                      const int64_t* __restrict__ cache_indices,
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(GQ_THREADS) void attn_decode_gqa_kernel(const uint1
         }
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < grp * D; idx += GQ_THREADS) {
+    for (int idx = threadIdx.x; idx < grp * D; idx += GQ_WAVES * 64) {
         const int head = idx / D, d = idx - head * D;
         float mm = -1e30f;
         for (int w = 0; w < GQ_WAVES; ++w) mm = fmaxf(mm, mg[(w * 16 + head) * (D + 2) + D]);
@@ -414,20 +420,23 @@ hipError_t launch_attn_decode_gqa(hipStream_t s, const uint16_t* qkv, const KvAd
     if (nb == 0) return hipSuccess;
     if (!attn_decode_gqa_supported(quant_bit, H, Hkv, D)) return hipErrorInvalidValue;
     dim3 grid((unsigned)Hkv, (unsigned)nb, (unsigned)split);
-#define GQ_LAUNCH(QB, DD, MD)                                                                                                     \
+    static const int small_min = getenv("PPLHIP_GQA_SMALL_BLOCK_MIN") ? atoi(getenv("PPLHIP_GQA_SMALL_BLOCK_MIN")) : GQ_SMALL_BLOCK_MIN;   // A/B runs
+    const bool small = (int64_t)Hkv * nb * split >= small_min;
+#define GQ_LAUNCH(QB, DD, MD, NW)                                                                                                 \
     do {                                                                                                                          \
-        gq_set_lds((const void*)attn_decode_gqa_kernel<QB, DD, MD>, gq_lds_bytes<QB, DD>());                                     \
+        gq_set_lds((const void*)attn_decode_gqa_kernel<QB, DD, MD, NW>, gq_lds_bytes<QB, DD, NW>());                             \
         if (t0 && t1)                                                                                                             \
-            hipExtLaunchKernelGGL((attn_decode_gqa_kernel<QB, DD, MD>), grid, dim3(GQ_THREADS), (gq_lds_bytes<QB, DD>()), s, t0, t1, 0, qkv, kv, seq_starts, \
-                                  start_pos, cache_indices, max_pages, H, Hkv, split, workspace, out);                            \
+            hipExtLaunchKernelGGL((attn_decode_gqa_kernel<QB, DD, MD, NW>), grid, dim3(NW * 64), (gq_lds_bytes<QB, DD, NW>()), s, t0, t1, 0, qkv, kv, \
+                                  seq_starts, start_pos, cache_indices, max_pages, H, Hkv, split, workspace, out);               \
         else                                                                                                                      \
-            hipLaunchKernelGGL((attn_decode_gqa_kernel<QB, DD, MD>), grid, dim3(GQ_THREADS), (gq_lds_bytes<QB, DD>()), s, qkv, kv, seq_starts, start_pos, \
-                               cache_indices, max_pages, H, Hkv, split, workspace, out);                                          \
+            hipLaunchKernelGGL((attn_decode_gqa_kernel<QB, DD, MD, NW>), grid, dim3(NW * 64), (gq_lds_bytes<QB, DD, NW>()), s, qkv, kv, seq_starts, \
+                               start_pos, cache_indices, max_pages, H, Hkv, split, workspace, out);                              \
     } while (0)
-#define GQ_CASE(QB, DD)                                                              \
-    if (quant_bit == QB && D == DD) {                                                \
-        if (kv.mode == 0) GQ_LAUNCH(QB, DD, 0); else GQ_LAUNCH(QB, DD, 1);           \
-        return hipGetLastError();                                                    \
+#define GQ_CASE(QB, DD)                                                                                          \
+    if (quant_bit == QB && D == DD) {                                                                            \
+        if (small) { if (kv.mode == 0) GQ_LAUNCH(QB, DD, 0, GQ_WAVES_SMALL); else GQ_LAUNCH(QB, DD, 1, GQ_WAVES_SMALL); } \
+        else { if (kv.mode == 0) GQ_LAUNCH(QB, DD, 0, GQ_WAVES_BIG); else GQ_LAUNCH(QB, DD, 1, GQ_WAVES_BIG); }   \
+        return hipGetLastError();                                                                                \
     }
     GQ_CASE(8, 128) GQ_CASE(0, 128) GQ_CASE(8, 64) GQ_CASE(0, 64) GQ_CASE(0, 32)
 #undef GQ_CASE
