@@ -104,6 +104,14 @@ def test_config4_decode_attention_batch_256_gqa_8_to_1_kv_2000_paged():
     _decode_attention_case("config4_attn_decode_b256_gqa8", 256, 8, 1, 1900, 2100, 1, 41)
 
 
+@pytest.mark.parametrize("B,kv_lo,kv_hi,mode", [(600, 40, 330, 1), (520, 1, 97, 0), (1024, 500, 530, 1)])
+def test_grouped_query_decode_attention_four_wave_blocks(B, kv_lo, kv_hi, mode):
+    """round 6: launches of >= 512 (KV head, request, split) blocks run the grouped-query decode kernel on 4-wave blocks, two per CU (a wave
+    then owns every fourth 16-key sub-tile instead of every eighth, the merge takes four partial states); 8 query heads on one KV head,
+    ragged short contexts (incl. kv 1: a single pair step that is mostly mask), contiguous and paged"""
+    _decode_attention_case(f"gqa_four_wave_blocks_b{B}_kv{kv_lo}_{kv_hi}_mode{mode}", B, 8, 1, kv_lo, kv_hi, mode, B + kv_hi)
+
+
 def _linear_case(name, wq, M, N, K, swiglu, seed):
     m = load_pplhip()
     rng = np.random.RandomState(seed)
