@@ -729,6 +729,11 @@ hipError_t launch_linear(hipStream_t s, const uint16_t* x, const void* w, const 
     dim3 grid((unsigned)(n_tiles_pad * m_tiles)), block(256);
     static const int min_m256 = tune_int("PPLHIP_GEMM_256_MIN_M", 3584);  // measured (7B layer): M = 3584 1435 vs 1501 us, 3072 1277 vs 1264, 2560 equal, 2048 941 vs 851
     if (wq_bit == 8 && K % G_BK == 0 && M >= min_m256 && N >= 1024 && !force_generic) {
+        // (Round 6, measured and not adopted: the same block tile on v_mfma_f32_32x32x16_f16 -- four waves of 64 (n) x 256 (m) with 256 resident
+        // accumulators, or this kernel's eight waves of 32 x 256 -- with two rolling fragment sets and LDS-DMA pieces on a scalar base: a third
+        // fewer instructions per flop, parity-green, and 13 % SLOWER (1.05-1.06 against 1.21 PFLOP/s at M = 8192, profiles/r06_gemm_big_ab.log).
+        // The counters that motivated it -- 2.25 other instructions per MFMA here against 0.72 in the vendor library's kernel, same L2 hit rates,
+        // same bytes -- are in profiles/r06_gemm_bigm_counters.md; the kernel is kept under profiles/probes/gemm_big/.)
         const int nt2 = (N + H_BN - 1) / H_BN, mt2 = (int)((M + H_BM - 1) / H_BM);
         const size_t lds = (size_t)H_ST * (H_BM * G_BK * 2 + H_BN * G_BK);
         // super-tile shape: gm = the largest divisor of mt2 <= 4 (X tiles carry twice the bytes of W tiles), gn = up to 8 weight tiles
