@@ -15,7 +15,9 @@ for B, KV in ((256, 2048), (512, 1024), (1024, 512), (256, 4096), (256, 1024)):
 PY
 }
 for rep in 1 2; do
-  cp $GRAFT_REPO_ROOT/profiles/probes/(git show 3c9...:csrc/k_attn_decode_gqa.hip) k_attn_decode_gqa.hip; make -s -j16 >/dev/null 2>&1; echo "== pair steps v1 (rep $rep)"; run
+  # (v1 = the pair-step kernel as committed: the box has no .git -- save `git show HEAD:ppl.llm.serving_amd/csrc/k_attn_decode_gqa.hip` as
+  #  profiles/probes/k_attn_decode_gqa_pair_v1.hip.txt before sending the tree)
+  cp $GRAFT_REPO_ROOT/profiles/probes/k_attn_decode_gqa_pair_v1.hip.txt k_attn_decode_gqa.hip; make -s -j16 >/dev/null 2>&1; echo "== pair steps v1 (rep $rep)"; run
   cp /tmp/gq_new.hip k_attn_decode_gqa.hip; make -s -j16 >/dev/null 2>&1; echo "== HEAD (rep $rep)"; run
 done
 cd $GRAFT_REPO_ROOT
