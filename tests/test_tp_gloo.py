@@ -3,7 +3,9 @@
      all-gather inside ref_forward) equals the unsharded oracle;
   2. world_size 2 over gloo: two PROCESSES each own one slice, run the per-rank half of every layer with the oracle's
      operators in exactly the order libpplhip's pplhip_run issues them, exchange through torch.distributed
-     (all_reduce of the row-parallel outputs, all_gather of the vocab shards) and reproduce the unsharded logits;
+     (all_reduce of the row-parallel outputs, all_gather of the vocab shards) and reproduce the unsharded logits -- in both step schedules:
+     all-reduce + replicated norm (RCCL), and the direct collectives' sequence-parallel residual stream (reduce-scatter by rows, residual add +
+     RMSNorm on the owned rows, all-gather of normed rows: csrc/k_comm.hip p2p_allreduce_norm_kernel, round 6);
   3. bench.py's multi-process control plane (rendezvous, unique-id broadcast, MAX-over-ranks timing) in --dry-run."""
 import ctypes as C
 import json
@@ -85,26 +87,56 @@ def lin(x, name, N, K, out32=0):
     return y
 def allreduce(x):                      # ncclAllReduce(fp16) of pplhip_run
     t = torch.from_numpy(x.copy()); dist.all_reduce(t); return rh(t.numpy())
+FUSED = len(sys.argv) > 3 and sys.argv[3] == "fused"
+per = (T + world - 1) // world
+lo, hi = min(per * rank, T), min(per * rank + per, T)
+def allreduce_norm(partial, h, wname):
+    """the direct collectives' fused form (csrc/k_comm.hip p2p_allreduce_norm_kernel): reduce-scatter by ROWS (rank r owns rows [r per,
+    (r + 1) per)), residual add + RMSNorm on the owned rows only, all-gather of the NORMED rows; h is valid on the owned rows only"""
+    parts = [torch.zeros(per, hd) for _ in range(world)]
+    padded = np.zeros((per * world, hd), dtype=np.float32); padded[:T] = partial
+    mine = torch.zeros(per, hd)
+    dist.reduce_scatter(mine, [torch.from_numpy(padded[r * per:(r + 1) * per].copy()) for r in range(world)])
+    s_own = rh(mine.numpy())[:hi - lo]                                   # fp16(sum over ranks) of MY rows
+    xn_own, h_own = f32(hi - lo, hd), np.ascontiguousarray(h[lo:hi])
+    if hi > lo:
+        L.ref_rmsnorm(p(h_own), p(np.ascontiguousarray(s_own)), p(sl.get_tensor(wname, np.float16)), desc.norm_eps, hi - lo, hd, p(xn_own), p(h_own))
+    h[lo:hi] = h_own                                                     # the residual stream: my rows only
+    send = torch.zeros(per, hd); send[:hi - lo] = torch.from_numpy(xn_own)
+    got = [torch.zeros(per, hd) for _ in range(world)]
+    dist.all_gather(got, send)
+    return np.ascontiguousarray(torch.cat(got, 0).numpy()[:T])
 rope = f32(desc.max_position, D); L.ref_build_rope_table(p(rope), desc.max_position, D, desc.rope_theta)
 h = f32(T, hd); L.ref_embedding(p(tok), p(sl.get_tensor("tok_embeddings.weight", np.float16)), T, hd, p(h))
 pending = None
+xn = f32(T, hd)
 for l in range(desc.num_layers):
-    xn = f32(T, hd)
-    L.ref_rmsnorm(p(h), None if pending is None else p(pending), p(sl.get_tensor(f"layers.{l}.attention_norm.weight", np.float16)),
-                  desc.norm_eps, T, hd, p(xn), p(h))
+    if not FUSED or l == 0:
+        L.ref_rmsnorm(p(h), None if pending is None else p(pending), p(sl.get_tensor(f"layers.{l}.attention_norm.weight", np.float16)),
+                      desc.norm_eps, T, hd, p(xn), p(h))
     qkv = lin(xn, f"layers.{l}.attention.wqkv", (H + 2 * Hkv) * D, hd)
     L.ref_rope_kv_write(p(qkv), p(rope), C.byref(desc), H, Hkv, D, l, L.ref_kv_ptr(sl.h, 0), L.ref_kv_ptr(sl.h, 1), 64,
                         p(ss), p(sp), p(ci), 0, B)
     att = f32(T, H * D)
     L.ref_attention(p(qkv), C.byref(desc), H, Hkv, D, l, L.ref_kv_ptr(sl.h, 0), L.ref_kv_ptr(sl.h, 1), 64, p(ss), p(sp), p(ci), 0, B, p(att))
-    part = allreduce(lin(att, f"layers.{l}.attention.wo", hd, H * D))
-    L.ref_rmsnorm(p(h), p(part), p(sl.get_tensor(f"layers.{l}.ffn_norm.weight", np.float16)), desc.norm_eps, T, hd, p(xn), p(h))
+    if FUSED:
+        xn = allreduce_norm(lin(att, f"layers.{l}.attention.wo", hd, H * D), h, f"layers.{l}.ffn_norm.weight")
+    else:
+        part = allreduce(lin(att, f"layers.{l}.attention.wo", hd, H * D))
+        L.ref_rmsnorm(p(h), p(part), p(sl.get_tensor(f"layers.{l}.ffn_norm.weight", np.float16)), desc.norm_eps, T, hd, p(xn), p(h))
     gu = lin(xn, f"layers.{l}.feed_forward.w13", 2 * inter, hd)
     act = f32(T, inter); L.ref_silu_mul(p(gu), T, inter, p(act))
-    pending = allreduce(lin(act, f"layers.{l}.feed_forward.w2", hd, inter))
+    if FUSED:   # the collective behind w2 normalises for the NEXT consumer: the next layer's attention norm, or the final norm
+        nxt = f"layers.{l + 1}.attention_norm.weight" if l + 1 < desc.num_layers else "norm.weight"
+        xn = allreduce_norm(lin(act, f"layers.{l}.feed_forward.w2", hd, inter), h, nxt)
+    else:
+        pending = allreduce(lin(act, f"layers.{l}.feed_forward.w2", hd, inter))
 last = ss[1:] - 1
-hl, pl, hn = np.ascontiguousarray(h[last]), np.ascontiguousarray(pending[last]), f32(B, hd)
-L.ref_rmsnorm(p(hl), p(pl), p(sl.get_tensor("norm.weight", np.float16)), desc.norm_eps, B, hd, p(hn), None)
+if FUSED:
+    hn = np.ascontiguousarray(xn[last])                                  # the final norm already ran on every row: last-token gather only
+else:
+    hl, pl, hn = np.ascontiguousarray(h[last]), np.ascontiguousarray(pending[last]), f32(B, hd)
+    L.ref_rmsnorm(p(hl), p(pl), p(sl.get_tensor("norm.weight", np.float16)), desc.norm_eps, B, hd, p(hn), None)
 mine = torch.from_numpy(lin(hn, "output", vl, hd, 1))
 shards = [torch.empty_like(mine) for _ in range(world)]
 dist.all_gather(shards, mine)          # ncclAllGather + strided copies of pplhip_run
@@ -115,7 +147,10 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-def test_world_size_2_gloo_matches_unsharded(golden_dir, tmp_path):
+@pytest.mark.parametrize("schedule", ["plain", "fused"])
+def test_world_size_2_gloo_matches_unsharded(golden_dir, tmp_path, schedule):
+    """plain: all-reduce + replicated (Skip)RMSNorm (RCCL's schedule); fused: the direct collectives' sequence-parallel residual stream
+    (reduce-scatter by rows, residual add + norm on the owned rows, all-gather of normed rows, last-token gather from the gathered matrix)"""
     desc, weights, prompts = _setup(golden_dir)
     full = ref.RefModel(desc)
     for k, v in weights.items():
@@ -127,7 +162,8 @@ def test_world_size_2_gloo_matches_unsharded(golden_dir, tmp_path):
     out = tmp_path / "logits.npy"
     env = dict(os.environ, OMP_NUM_THREADS="2")
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                           "127.0.0.1", "--master-port", "29631", str(script), ROOT, str(out)], env=env, timeout=600,
+                           "127.0.0.1", "--master-port", "29631" if schedule == "plain" else "29633", str(script), ROOT, str(out), schedule],
+                          env=env, timeout=600,
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     got = np.load(out)
     assert np.abs(got - want).max() < 4e-3 * max(1.0, np.abs(want).max())
