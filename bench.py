@@ -403,63 +403,74 @@ def run(args, guard, world, rank, local_rank):
                        cache_quant_group=8 if args.kv_quant else 1, cache_layout=3, cache_mode=args.cache_mode,
                        page_size=16 if args.cache_mode else 0,
                        weight_quant_bit=args.weight_quant, act_quant_bit=args.act_quant, **mk)
-    uid = None
-    p2p_only = os.environ.get("PPLHIP_COMM") == "p2p"
-    guard.at("RCCL unique-id broadcast")
-    if world > 1 and not p2p_only:
-        box = [P.get_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        uid = box[0]
-    elif args.emulate_tp > 1:
-        os.environ["PPLHIP_EMULATE_TP"] = "1"
-    elif os.environ.get("PPLHIP_FORCE_COMM"):
-        uid = P.get_unique_id()  # single-GPU self-test of the RCCL path (world size 1: every collective is an identity)
+    # ---- bring-up (context, collectives, weights, KV slab), warm-up, and -- N > 1 only -- ONE retry on RCCL when the warm-up steps fail on the
+    # direct collectives although their self-test passed (first contact with real links: a timed-out spin, a device error).  Every rank
+    # takes the same decision (gloo MIN over "my warm-up ran"); the retry is reported in collectives.fallbacks.  Failures BEFORE the
+    # warm-up (rendezvous, init, handle exchange, self-test) are the start-up guard's business, not retried.
+    ctx = collectives = comm_mode = uid = None
     tp = args.emulate_tp if args.emulate_tp > 1 else world
-    # PPLHIP_BENCH_ONE_DEVICE=1 (tests): every rank on device 0 -- the multi-process plumbing (IPC handles, direct
-    # collectives) on a one-GPU box; needs PPLHIP_COMM=p2p because RCCL refuses two ranks on one device
-    dev = 0 if os.environ.get("PPLHIP_BENCH_ONE_DEVICE") else local_rank
-    guard.at("pplhip_init (streams, RCCL communicator, buffers)")
-    ctx = P.Context(desc, max_running_batch=B, max_tokens_per_step=max(8192, B), n_local_ranks=1, world_size=tp,
-                    rank_base=rank, device_ids=[dev], unique_id=uid, profiling=1 if args.breakdown else 2, tpb=args.tpb)
-    if world > 1 and os.environ.get("PPLHIP_COMM") != "rccl":
-        # one process per GPU: exchange the IPC handles of the exchange regions, then the collective self-test decides
-        # between the direct kernels and RCCL (the same decision on every rank)
-        handles = [None] * world
-        guard.at("IPC-handle exchange")
-        try:
-            mine = ctx.comm_export(0)
-        except RuntimeError as e:   # no IPC handle for the exchange region on this rank: every rank then stays on RCCL
-            print(f"[bench] rank {rank}: {e}", file=sys.stderr)
-            mine = None
-        dist.all_gather_object(handles, mine)
-        if all(h is not None for h in handles):
-            guard.at("pplhip_comm_connect (peer mapping + collective self-test)")
-            ctx.comm_connect(handles)
-    comm_mode = {0: "none", 1: "rccl", 2: "direct xGMI kernels (two-shot, all links)"}[ctx.comm_mode()]
-    # what this run's collectives are and cost (outside the timed region): mode, self-test verdict, schedule of the timed step, fallbacks
-    # taken, and a timed micro-loop of the step's own all-reduce message on the chosen path AND on RCCL -- so that a bad scaling curve can
-    # be read from the JSON line alone
-    collectives = ctx.comm_info(B)
-    guard.info = collectives
-    guard.at("timed all-reduce micro-loop")
-    if world > 1 or os.environ.get("PPLHIP_FORCE_COMM"):
-        try:
-            collectives["allreduce_us"] = {"rows": B, "bytes": B * desc.hidden_dim * 2, "chosen_path": ctx.comm_allreduce_us(B, 20, 0),
-                                           "rccl": ctx.comm_allreduce_us(B, 20, 1)}
-        except Exception as e:   # reporting only
-            collectives["allreduce_us"] = {"error": repr(e)}
-    guard.at("weights and KV slab")
-    ctx.init_synthetic(0, 1234)
-    kv_tokens = B * total_len if args.cache_mode == 0 else B * ((total_len + 15) // 16) * 16
-    rag_kv = ragged_kv_lengths(B) if (args.ragged_steps > 0 and args.cache_mode == 0) else None
-    if rag_kv is not None:  # the ragged leg re-plans the same slab: request b owns kv_b + steps + 1 contiguous slots
-        kv_tokens = max(kv_tokens, int((rag_kv + args.ragged_steps + 1).sum()))
-    cap = ctx.kv_capacity(0.94)
-    if kv_tokens > cap:
-        sys.exit(f"KV slab needs {kv_tokens} tokens but only {cap} fit")
-    ctx.kv_alloc(0, kv_tokens)
-    ctx.kv_fill_synthetic(0, 99)
-    H, Hkv, D = desc.num_heads // tp, desc.num_kv_heads // tp, desc.hidden_dim // desc.num_heads
+    kv_tokens = rag_kv = None
+    H = Hkv = D = 0
+
+    def bring_up():
+        nonlocal ctx, collectives, comm_mode, uid, kv_tokens, rag_kv, H, Hkv, D
+        uid = None
+        p2p_only = os.environ.get("PPLHIP_COMM") == "p2p"
+        guard.at("RCCL unique-id broadcast")
+        if world > 1 and not p2p_only:
+            box = [P.get_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            uid = box[0]
+        elif args.emulate_tp > 1:
+            os.environ["PPLHIP_EMULATE_TP"] = "1"
+        elif os.environ.get("PPLHIP_FORCE_COMM"):
+            uid = P.get_unique_id()  # single-GPU self-test of the RCCL path (world size 1: every collective is an identity)
+        # PPLHIP_BENCH_ONE_DEVICE=1 (tests): every rank on device 0 -- the multi-process plumbing (IPC handles, direct
+        # collectives) on a one-GPU box; needs PPLHIP_COMM=p2p because RCCL refuses two ranks on one device
+        dev = 0 if os.environ.get("PPLHIP_BENCH_ONE_DEVICE") else local_rank
+        guard.at("pplhip_init (streams, RCCL communicator, buffers)")
+        ctx = P.Context(desc, max_running_batch=B, max_tokens_per_step=max(8192, B), n_local_ranks=1, world_size=tp,
+                        rank_base=rank, device_ids=[dev], unique_id=uid, profiling=1 if args.breakdown else 2, tpb=args.tpb)
+        if world > 1 and os.environ.get("PPLHIP_COMM") != "rccl":
+            # one process per GPU: exchange the IPC handles of the exchange regions, then the collective self-test decides
+            # between the direct kernels and RCCL (the same decision on every rank)
+            handles = [None] * world
+            guard.at("IPC-handle exchange")
+            try:
+                mine = ctx.comm_export(0)
+            except RuntimeError as e:   # no IPC handle for the exchange region on this rank: every rank then stays on RCCL
+                print(f"[bench] rank {rank}: {e}", file=sys.stderr)
+                mine = None
+            dist.all_gather_object(handles, mine)
+            if all(h is not None for h in handles):
+                guard.at("pplhip_comm_connect (peer mapping + collective self-test)")
+                ctx.comm_connect(handles)
+        comm_mode = {0: "none", 1: "rccl", 2: "direct xGMI kernels (two-shot, all links)"}[ctx.comm_mode()]
+        # what this run's collectives are and cost (outside the timed region): mode, self-test verdict, schedule of the timed step, fallbacks
+        # taken, and a timed micro-loop of the step's own all-reduce message on the chosen path AND on RCCL -- so that a bad scaling curve can
+        # be read from the JSON line alone
+        collectives = ctx.comm_info(B)
+        guard.info = collectives
+        guard.at("timed all-reduce micro-loop")
+        if world > 1 or os.environ.get("PPLHIP_FORCE_COMM"):
+            try:
+                collectives["allreduce_us"] = {"rows": B, "bytes": B * desc.hidden_dim * 2, "chosen_path": ctx.comm_allreduce_us(B, 20, 0),
+                                               "rccl": ctx.comm_allreduce_us(B, 20, 1)}
+            except Exception as e:   # reporting only
+                collectives["allreduce_us"] = {"error": repr(e)}
+        guard.at("weights and KV slab")
+        ctx.init_synthetic(0, 1234)
+        kv_tokens = B * total_len if args.cache_mode == 0 else B * ((total_len + 15) // 16) * 16
+        rag_kv = ragged_kv_lengths(B) if (args.ragged_steps > 0 and args.cache_mode == 0) else None
+        if rag_kv is not None:  # the ragged leg re-plans the same slab: request b owns kv_b + steps + 1 contiguous slots
+            kv_tokens = max(kv_tokens, int((rag_kv + args.ragged_steps + 1).sum()))
+        cap = ctx.kv_capacity(0.94)
+        if kv_tokens > cap:
+            sys.exit(f"KV slab needs {kv_tokens} tokens but only {cap} fit")
+        ctx.kv_alloc(0, kv_tokens)
+        ctx.kv_fill_synthetic(0, 99)
+        H, Hkv, D = desc.num_heads // tp, desc.num_kv_heads // tp, desc.hidden_dim // desc.num_heads
+
 
     rng = np.random.RandomState(1234)
     cache_idx = (np.arange(B, dtype=np.int64) * total_len)
@@ -485,10 +496,46 @@ def run(args, guard, world, rank, local_rank):
         out, _ = ctx.sample(B, top_k=1, req_list_changed=(i == 0))
         return out.astype(np.int64)
 
-    guard.at("warm-up steps")
-    for i in range(W):
-        tok = step(i, tok)
-    barrier()
+
+    def agree(ok):
+        if dist is None:
+            return ok
+        import torch
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    tok0 = tok.copy()
+    bench_fallback = ""
+    retry_to = os.environ.get("PPLHIP_BENCH_FALLBACK_TO", "rccl")        # (tests on one device retry on "p2p": RCCL refuses two ranks per device)
+    may_retry = world > 1 and not args.emulate_tp and (os.environ.get("PPLHIP_COMM", "auto") in ("auto", "") or "PPLHIP_BENCH_FALLBACK_TO" in os.environ)
+    for attempt in range(2):
+        bring_up()
+        if bench_fallback:
+            collectives["fallbacks"] = (collectives.get("fallbacks", "") + " | " if collectives.get("fallbacks") else "") + bench_fallback
+            guard.info = collectives
+        guard.at("warm-up steps" + (" (retry)" if attempt else ""))
+        err, tok = None, tok0.copy()
+        try:
+            if attempt == 0 and os.environ.get("PPLHIP_BENCH_FAIL_WARMUP_ONCE") == str(rank):   # test hook: this rank's first warm-up fails
+                raise RuntimeError("injected warm-up failure (PPLHIP_BENCH_FAIL_WARMUP_ONCE)")
+            for i in range(W):
+                tok = step(i, tok)
+            ctx.sync(0)
+        except Exception as e:
+            err = f"{type(e).__name__}: {str(e)[:200]}"
+            print(f"[bench] rank {rank}: warm-up failed on '{comm_mode}': {err}", file=sys.stderr, flush=True)
+        if agree(err is None):                   # (doubles as the barrier behind the warm-up)
+            break
+        if attempt == 1 or not may_retry or ctx.comm_mode() != 2:
+            raise RuntimeError(f"warm-up steps failed on {comm_mode}: {err or 'on another rank'}")
+        bench_fallback = f"bench: warm-up steps failed on the direct collectives ({err or 'on another rank'}): every rank re-initialised on {retry_to}"
+        print(f"[bench] rank {rank}: {bench_fallback}", file=sys.stderr, flush=True)
+        try:
+            ctx.close()
+        except Exception:
+            pass
+        os.environ["PPLHIP_COMM"] = retry_to
     guard.disarm()   # every rank is past its first steps: from here a failure is a step failure and raises as such
     ctx.profile_reset(0)
     t0 = time.perf_counter()

@@ -318,3 +318,27 @@ def test_one_process_per_rank_over_ipc_handles():
     assert len(line) == 1, out.stdout.decode()[-2000:]
     res = json.loads(line[0])
     assert res["n_gpus"] == 2 and res["value"] > 0 and res["config"]["collectives"].startswith("direct")
+
+
+def test_bench_retries_on_another_path_when_the_warm_up_fails_on_the_direct_collectives():
+    """round 6: first contact with real links may pass the collectives' self-test and still fail in the first real steps (a spin that times
+    out, a device error).  bench.py --gpus N then takes ONE retry: every rank agrees (gloo MIN) that the warm-up failed, closes its context and
+    re-initialises on RCCL -- here, with both ranks on one device where RCCL cannot run, on the direct collectives again (test hook
+    PPLHIP_BENCH_FALLBACK_TO=p2p), after rank 1's first warm-up was made to fail (PPLHIP_BENCH_FAIL_WARMUP_ONCE=1: rank 0 then really times out
+    in its all-reduce).  The run must complete and say what happened in collectives.fallbacks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PPLHIP_COMM="p2p", PPLHIP_BENCH_ONE_DEVICE="1", OMP_NUM_THREADS="1", PPLHIP_P2P_TIMEOUT_MS="4000", PPLHIP_BENCH_FAIL_WARMUP_ONCE="1",
+               PPLHIP_BENCH_FALLBACK_TO="p2p")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--layers", "2",
+                          "--batch", "64", "--kv-len", "64", "--no-cpu-baseline", "--prefill-sample", "0", "--ragged-steps", "0"], env=env, timeout=900,
+                         capture_output=True)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    line = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(line) == 1, out.stdout.decode()[-2000:]
+    res = json.loads(line[0])
+    assert res["n_gpus"] == 2 and res["value"] > 0 and "error" not in res
+    assert "warm-up steps failed on the direct collectives" in res["collectives"]["fallbacks"] and "re-initialised on p2p" in res["collectives"]["fallbacks"]
